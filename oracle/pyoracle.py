@@ -1,0 +1,189 @@
+"""ctypes bridge to the CPU oracle (libsfm_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under sfm_amd/ imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsfm_oracle.so")
+
+DMATCH_DTYPE = np.dtype(
+    [("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")]
+)
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "--no-print-directory"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        c = ctypes
+        vp = c.c_void_p
+        L.oracle_knn_match.argtypes = [vp, c.c_int, c.c_size_t, vp, c.c_int, c.c_size_t,
+                                       c.c_int, c.c_int, vp, vp, c.c_int]
+        L.oracle_knn_match.restype = c.c_int
+        L.oracle_ratio_test.argtypes = [vp, vp, c.c_int, c.c_int, c.c_double, vp]
+        L.oracle_ratio_test.restype = c.c_int
+        L.oracle_rng_next.argtypes = [c.c_uint64, c.c_int, vp]
+        L.oracle_rng_uniform.argtypes = [c.c_uint64, c.c_int, c.c_int, c.c_int, vp]
+        L.oracle_sample_table.argtypes = [c.c_int, c.c_int, c.c_int, vp]
+        L.oracle_sample_table.restype = c.c_int
+        L.oracle_sample_table_f.argtypes = [c.c_int, vp, vp, c.c_int, vp]
+        L.oracle_sample_table_f.restype = c.c_int
+        L.oracle_ransac_update_num_iters.argtypes = [c.c_double, c.c_double, c.c_int, c.c_int]
+        L.oracle_ransac_update_num_iters.restype = c.c_int
+        L.oracle_five_point.argtypes = [vp, vp, vp]
+        L.oracle_five_point.restype = c.c_int
+        L.oracle_seven_point.argtypes = [vp, vp, vp]
+        L.oracle_seven_point.restype = c.c_int
+        L.oracle_sampson_errors.argtypes = [vp, vp, vp, c.c_int, vp]
+        L.oracle_symepi_errors.argtypes = [vp, vp, vp, c.c_int, vp]
+        L.oracle_normalize_points.argtypes = [vp, c.c_int, vp, c.c_double, vp]
+        L.oracle_normalize_points.restype = c.c_double
+        L.oracle_ransac.argtypes = [c.c_int, vp, vp, c.c_int, vp, c.c_double, c.c_double,
+                                    c.c_int, c.c_int, vp, vp, vp, vp, vp, vp]
+        L.oracle_ransac.restype = c.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def knn_match(query, train, k=2, nthreads=1):
+    """query, train: 2-D float32 arrays (row strides honoured).  Returns
+    (matches[nq,k] structured, counts[nq])."""
+    query = np.asarray(query)
+    train = np.asarray(train)
+    assert query.dtype == np.float32 and train.dtype == np.float32
+    nq, dim = query.shape
+    nt = train.shape[0]
+    assert train.shape[1] == dim or nt == 0
+    assert query.strides[1] == 4 and (nt == 0 or train.strides[1] == 4)
+    out = np.zeros((nq, k), dtype=DMATCH_DTYPE)
+    counts = np.zeros(nq, dtype=np.int32)
+    rc = lib().oracle_knn_match(_p(query), nq, query.strides[0] if nq else 4 * dim,
+                                _p(train), nt, train.strides[0] if nt else 4 * dim,
+                                dim, k, _p(out), _p(counts), nthreads)
+    assert rc == 0
+    return out, counts
+
+
+def ratio_test(matches, counts, ratio=0.7):
+    nq, k = matches.shape
+    keep = np.zeros(nq, dtype=np.int32)
+    n = lib().oracle_ratio_test(_p(np.ascontiguousarray(matches)), _p(counts), nq, k, ratio, _p(keep))
+    return keep[:n].copy()
+
+
+def rng_next(n, seed=0xFFFFFFFFFFFFFFFF):
+    out = np.zeros(n, dtype=np.uint32)
+    lib().oracle_rng_next(seed, n, _p(out))
+    return out
+
+
+def rng_uniform(a, b, n, seed=0xFFFFFFFFFFFFFFFF):
+    out = np.zeros(n, dtype=np.int32)
+    lib().oracle_rng_uniform(seed, a, b, n, _p(out))
+    return out
+
+
+def sample_table(count, m, n_iters):
+    out = np.zeros((n_iters, m), dtype=np.int32)
+    rc = lib().oracle_sample_table(count, m, n_iters, _p(out))
+    assert rc == 0
+    return out
+
+
+def sample_table_f(pts1, pts2, n_iters):
+    pts1 = np.ascontiguousarray(pts1, dtype=np.float32)
+    pts2 = np.ascontiguousarray(pts2, dtype=np.float32)
+    out = np.zeros((n_iters, 7), dtype=np.int32)
+    got = lib().oracle_sample_table_f(pts1.shape[0], _p(pts1), _p(pts2), n_iters, _p(out))
+    return out[:max(got, 0)]
+
+
+def update_num_iters(p, ep, m, max_iters):
+    return lib().oracle_ransac_update_num_iters(p, ep, m, max_iters)
+
+
+def five_point(x1, x2):
+    x1 = np.ascontiguousarray(x1, dtype=np.float64)
+    x2 = np.ascontiguousarray(x2, dtype=np.float64)
+    models = np.zeros((10, 3, 3), dtype=np.float64)
+    n = lib().oracle_five_point(_p(x1), _p(x2), _p(models))
+    return models[:n].copy()
+
+
+def seven_point(x1, x2):
+    x1 = np.ascontiguousarray(x1, dtype=np.float32)
+    x2 = np.ascontiguousarray(x2, dtype=np.float32)
+    models = np.zeros((3, 3, 3), dtype=np.float64)
+    n = lib().oracle_seven_point(_p(x1), _p(x2), _p(models))
+    return models[:n].copy()
+
+
+def sampson_errors(E, x1, x2):
+    E = np.ascontiguousarray(E, dtype=np.float64)
+    x1 = np.ascontiguousarray(x1, dtype=np.float64)
+    x2 = np.ascontiguousarray(x2, dtype=np.float64)
+    err = np.zeros(x1.shape[0], dtype=np.float32)
+    lib().oracle_sampson_errors(_p(E), _p(x1), _p(x2), x1.shape[0], _p(err))
+    return err
+
+
+def symepi_errors(F, x1, x2):
+    F = np.ascontiguousarray(F, dtype=np.float64)
+    x1 = np.ascontiguousarray(x1, dtype=np.float32)
+    x2 = np.ascontiguousarray(x2, dtype=np.float32)
+    err = np.zeros(x1.shape[0], dtype=np.float32)
+    lib().oracle_symepi_errors(_p(F), _p(x1), _p(x2), x1.shape[0], _p(err))
+    return err
+
+
+def normalize_points(pts_px, K, threshold_px):
+    pts_px = np.ascontiguousarray(pts_px, dtype=np.float64)
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    out = np.zeros_like(pts_px)
+    thr = lib().oracle_normalize_points(_p(pts_px), pts_px.shape[0], _p(K), threshold_px, _p(out))
+    return out, thr
+
+
+MODEL_ESSENTIAL = 0
+MODEL_FUNDAMENTAL = 1
+
+
+def ransac(pts1, pts2, K=None, model=MODEL_ESSENTIAL, prob=0.99, threshold=1.0, max_iters=1000,
+           fixed_count=0, sample_table=None, mask_init=None, want_counts=False):
+    """Returns dict(ok, mask, model, n_inliers, iters, counts)."""
+    pts1 = np.ascontiguousarray(pts1, dtype=np.float64).reshape(-1, 2)
+    pts2 = np.ascontiguousarray(pts2, dtype=np.float64).reshape(-1, 2)
+    n = pts1.shape[0]
+    Kc = np.ascontiguousarray(K if K is not None else np.eye(3), dtype=np.float64)
+    mask = np.zeros(n, dtype=np.uint8) if mask_init is None else np.array(mask_init, dtype=np.uint8)
+    model_out = np.zeros((3, 3), dtype=np.float64)
+    n_inl = ctypes.c_int32(0)
+    iters = ctypes.c_int32(0)
+    nh = fixed_count if fixed_count > 0 else max(max_iters, 1)
+    counts = np.full((nh, 10), -2, dtype=np.int32) if want_counts else None
+    st = None
+    if sample_table is not None:
+        st = np.ascontiguousarray(sample_table, dtype=np.int32)
+    ok = lib().oracle_ransac(model, _p(pts1), _p(pts2), n, _p(Kc), prob, threshold, max_iters,
+                             fixed_count, _p(st), _p(mask), _p(model_out),
+                             ctypes.byref(n_inl), ctypes.byref(iters), _p(counts))
+    return dict(ok=ok, mask=mask, model=model_out, n_inliers=n_inl.value, iters=iters.value,
+                counts=counts)

@@ -1,0 +1,823 @@
+/*
+ * CPU ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see sfm_oracle.h).
+ *
+ * Plain C++17, no dependencies.  Build with -ffp-contract=off: several results
+ * below are compared bit-for-bit with the GPU path, and that requires that no
+ * multiply-add is fused on either side.
+ *
+ * What each part restates:
+ *   knn            cv::BFMatcher(NORM_L2)::knnMatch as called at
+ *                  /root/reference/main.cpp:184 (arithmetic: OpenCV 4.5.5
+ *                  core batchDistance: sqrtf of a float32 sum of squared
+ *                  differences, then a K-slot insertion scan in ascending
+ *                  train order with strict comparisons)
+ *   ratio test     /root/reference/main.cpp:189-197
+ *   rng/getSubset  cv::RNG and RANSACPointSetRegistrator::getSubset (OpenCV
+ *                  4.5.5 calib3d ptsetreg.cpp), reached from main.cpp:224
+ *   ransac         RANSACPointSetRegistrator::run + RANSACUpdateNumIters
+ *   five_point     Nister, "An efficient solution to the five-point relative
+ *                  pose problem", PAMI 2004 (the method behind
+ *                  cv::findEssentialMat, main.cpp:224)
+ *   sampson        EMEstimatorCallback::computeError (five-point.cpp)
+ *   seven_point    FMEstimatorCallback (fundam.cpp): 7-point solver and the
+ *                  symmetric epipolar distance of findFundamentalMat
+ *
+ * Deliberate, documented deviations where OpenCV's result is implementation
+ * defined or cannot be known without its source:
+ *   - null spaces come from Gauss-Jordan elimination with complete pivoting,
+ *     not from cv::SVD: the subspace is the same, the basis inside it is
+ *     arbitrary in both cases;
+ *   - polynomial real roots come from bracketing by derivative roots plus a
+ *     safeguarded Newton iteration, not cv::solvePoly; candidate models are
+ *     emitted in ascending root order (OpenCV's order is solvePoly's).
+ */
+#include "sfm_oracle.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------- k-NN ----
+
+void knn_rows(const float* query, int q0, int q1, size_t qstep,
+              const float* train, int nt, size_t tstep, int dim, int k,
+              oracle_dmatch* out, int32_t* counts)
+{
+    const int K = std::min(k, nt);
+    std::vector<float> buf(nt > 0 ? nt : 1);
+    std::vector<float> dist(k > 0 ? k : 1);
+    std::vector<int> nidx(k > 0 ? k : 1);
+    for (int i = q0; i < q1; i++) {
+        const float* q = (const float*)((const char*)query + (size_t)i * qstep);
+        for (int j = 0; j < nt; j++) {
+            const float* t = (const float*)((const char*)train + (size_t)j * tstep);
+            float s = 0.f;
+            for (int d = 0; d < dim; d++) {
+                float df = q[d] - t[d];
+                s += df * df;
+            }
+            buf[j] = std::sqrt(s);
+        }
+        for (int s = 0; s < k; s++) { dist[s] = FLT_MAX; nidx[s] = -1; }
+        if (K > 0) {
+            for (int j = 0; j < nt; j++) {
+                float d = buf[j];
+                if (d < dist[K - 1]) {
+                    int p = K - 2;
+                    for (; p >= 0 && dist[p] > d; p--) {
+                        dist[p + 1] = dist[p];
+                        nidx[p + 1] = nidx[p];
+                    }
+                    dist[p + 1] = d;
+                    nidx[p + 1] = j;
+                }
+            }
+        }
+        int cnt = 0;
+        for (int s = 0; s < k; s++) {
+            oracle_dmatch& m = out[(size_t)i * k + s];
+            m.queryIdx = i;
+            m.imgIdx = 0;
+            if (s < K && nidx[s] >= 0) {
+                m.trainIdx = nidx[s];
+                m.distance = dist[s];
+                cnt++;
+            } else {
+                m.trainIdx = -1;
+                m.distance = FLT_MAX;
+            }
+        }
+        counts[i] = cnt;
+    }
+}
+
+// ------------------------------------------------------------- cv::RNG ----
+
+struct CvRng {
+    uint64_t state;
+    explicit CvRng(uint64_t s) : state(s ? s : 0xffffffffULL) {}
+    uint32_t next()
+    {
+        state = (uint64_t)(uint32_t)state * 4164903690U + (uint32_t)(state >> 32);
+        return (uint32_t)state;
+    }
+    int uniform(int a, int b) { return a == b ? a : (int)(next() % (uint32_t)(b - a) + a); }
+};
+
+// ----------------------------------------------- small dense linear algebra
+
+// Null space of a rows x 9 system by Gauss-Jordan with complete pivoting.
+// On success basis holds (9-rows) vectors of 9 entries.  Pivot search scans
+// row-major and keeps the first maximum.
+bool null_space_9(const double* Ain, int rows, double* basis)
+{
+    double A[7][9];
+    int perm[9];
+    for (int i = 0; i < rows; i++)
+        for (int j = 0; j < 9; j++) A[i][j] = Ain[i * 9 + j];
+    for (int j = 0; j < 9; j++) perm[j] = j;
+    for (int p = 0; p < rows; p++) {
+        int bi = p, bj = p;
+        double best = -1.0;
+        for (int i = p; i < rows; i++)
+            for (int j = p; j < 9; j++) {
+                double v = std::fabs(A[i][j]);
+                if (v > best) { best = v; bi = i; bj = j; }
+            }
+        if (!(best > 0.0)) return false;
+        if (bi != p)
+            for (int j = 0; j < 9; j++) std::swap(A[p][j], A[bi][j]);
+        if (bj != p) {
+            for (int i = 0; i < rows; i++) std::swap(A[i][p], A[i][bj]);
+            std::swap(perm[p], perm[bj]);
+        }
+        double piv = A[p][p];
+        for (int j = p + 1; j < 9; j++) A[p][j] = A[p][j] / piv;
+        A[p][p] = 1.0;
+        for (int i = 0; i < rows; i++) {
+            if (i == p) continue;
+            double f = A[i][p];
+            for (int j = p + 1; j < 9; j++) A[i][j] = A[i][j] - f * A[p][j];
+            A[i][p] = 0.0;
+        }
+    }
+    const int nfree = 9 - rows;
+    for (int k = 0; k < nfree; k++) {
+        double* v = basis + k * 9;
+        for (int j = 0; j < 9; j++) v[j] = 0.0;
+        v[perm[rows + k]] = 1.0;
+        for (int i = 0; i < rows; i++) v[perm[i]] = -A[i][rows + k];
+    }
+    return true;
+}
+
+double horner(const double* c, int n, double x)
+{
+    double s = c[n];
+    for (int i = n - 1; i >= 0; i--) s = s * x + c[i];
+    return s;
+}
+
+// Root of polynomial P (degree n, derivative dP of degree n-1) inside the
+// bracket (lo,hi) with P(lo) of sign flo and a sign change across it.
+double solve_bracket(const double* P, const double* dP, int n, double lo, double hi, bool lo_neg)
+{
+    double x = 0.5 * (lo + hi);
+    for (int it = 0; it < 200; it++) {
+        double f = horner(P, n, x);
+        if (f == 0.0) return x;
+        if ((f < 0.0) == lo_neg) lo = x; else hi = x;
+        double df = horner(dP, n - 1, x);
+        double xn = x - f / df;
+        if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+        if (xn == x) return x;
+        if (!(xn > lo && xn < hi)) return x;  // bracket has no interior double left
+        x = xn;
+    }
+    return x;
+}
+
+// All real roots of c[0] + c[1] z + ... + c[n] z^n (n <= 10), ascending.
+// Level k of the recursion isolates the roots of the (n-k)-th derivative
+// between consecutive roots of the next derivative, where it is monotone.
+int real_roots(const double* cin, int n, double* roots)
+{
+    double c[11];
+    double cmax = 0.0;
+    for (int i = 0; i <= n; i++) cmax = std::max(cmax, std::fabs(cin[i]));
+    if (!(cmax > 0.0) || !std::isfinite(cmax)) return 0;
+    for (int i = 0; i <= n; i++) c[i] = cin[i] / cmax;
+    while (n > 0 && c[n] == 0.0) n--;
+    if (n == 0) return 0;
+    double D[11][11];
+    for (int i = 0; i <= n; i++) D[n][i] = c[i];
+    for (int k = n; k > 1; k--)
+        for (int i = 0; i < k; i++) D[k - 1][i] = (double)(i + 1) * D[k][i + 1];
+    double B = 0.0;
+    for (int i = 0; i < n; i++) B = std::max(B, std::fabs(c[i] / c[n]));
+    B = 1.0 + B;
+    if (!(B < 1e25)) B = 1e25;
+    double prev[10], cur[10];
+    int mprev = 1, mcur = 0;
+    prev[0] = -D[1][0] / D[1][1];
+    if (n == 1) { roots[0] = prev[0]; return 1; }
+    for (int k = 2; k <= n; k++) {
+        mcur = 0;
+        double lo = -B;
+        double flo = horner(D[k], k, lo);
+        for (int t = 0; t <= mprev; t++) {
+            double hi = (t < mprev) ? prev[t] : B;
+            if (hi > B) hi = B;
+            if (!(hi > lo)) continue;
+            double fhi = horner(D[k], k, hi);
+            if (flo == 0.0) {
+                if (mcur < 10) cur[mcur++] = lo;
+            } else if (fhi != 0.0 && ((flo < 0.0) != (fhi < 0.0))) {
+                if (mcur < 10) cur[mcur++] = solve_bracket(D[k], D[k - 1], k, lo, hi, flo < 0.0);
+            }
+            lo = hi;
+            flo = fhi;
+        }
+        if (flo == 0.0 && mcur < 10) cur[mcur++] = lo;
+        for (int i = 0; i < mcur; i++) prev[i] = cur[i];
+        mprev = mcur;
+        if (mprev == 0) {
+            // derivative chain lost its critical points: the polynomial is
+            // monotone from here on, keep going with a single interval
+        }
+    }
+    for (int i = 0; i < mprev; i++) roots[i] = prev[i];
+    return mprev;
+}
+
+// ---------------------------------------------------- five-point (Nister) --
+
+// Monomial bookkeeping for polynomials in (x,y,z).
+//   degree <= 1: [x, y, z, 1]
+//   degree <= 2: [x2, xy, xz, y2, yz, z2, x, y, z, 1]
+//   degree <= 3: Nister's elimination order
+//     [x3, y3, x2y, xy2, x2z, x2, y2z, y2, xyz, xy,
+//      xz2, xz, x, yz2, yz, y, z3, z2, z, 1]
+const int E1[4][3] = {{1,0,0},{0,1,0},{0,0,1},{0,0,0}};
+const int E2[10][3] = {{2,0,0},{1,1,0},{1,0,1},{0,2,0},{0,1,1},{0,0,2},{1,0,0},{0,1,0},{0,0,1},{0,0,0}};
+const int E3[20][3] = {{3,0,0},{0,3,0},{2,1,0},{1,2,0},{2,0,1},{2,0,0},{0,2,1},{0,2,0},{1,1,1},{1,1,0},
+                       {1,0,2},{1,0,1},{1,0,0},{0,1,2},{0,1,1},{0,1,0},{0,0,3},{0,0,2},{0,0,1},{0,0,0}};
+
+struct MonoTables {
+    int t11[4][4];
+    int t21[10][4];
+    MonoTables()
+    {
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                int e[3] = {E1[i][0] + E1[j][0], E1[i][1] + E1[j][1], E1[i][2] + E1[j][2]};
+                t11[i][j] = -1;
+                for (int m = 0; m < 10; m++)
+                    if (E2[m][0] == e[0] && E2[m][1] == e[1] && E2[m][2] == e[2]) t11[i][j] = m;
+            }
+        for (int i = 0; i < 10; i++)
+            for (int j = 0; j < 4; j++) {
+                int e[3] = {E2[i][0] + E1[j][0], E2[i][1] + E1[j][1], E2[i][2] + E1[j][2]};
+                t21[i][j] = -1;
+                for (int m = 0; m < 20; m++)
+                    if (E3[m][0] == e[0] && E3[m][1] == e[1] && E3[m][2] == e[2]) t21[i][j] = m;
+            }
+    }
+};
+const MonoTables MT;
+
+void mul11(const double* a, const double* b, double* out)
+{
+    for (int m = 0; m < 10; m++) out[m] = 0.0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) out[MT.t11[i][j]] = out[MT.t11[i][j]] + a[i] * b[j];
+}
+
+void mul21(const double* a, const double* b, double* out)
+{
+    for (int m = 0; m < 20; m++) out[m] = 0.0;
+    for (int i = 0; i < 10; i++)
+        for (int j = 0; j < 4; j++) out[MT.t21[i][j]] = out[MT.t21[i][j]] + a[i] * b[j];
+}
+
+// out[0..na+nb] = a * b, polynomials in z with c[i] the coefficient of z^i
+void pmul(const double* a, int na, const double* b, int nb, double* out)
+{
+    for (int i = 0; i <= na + nb; i++) out[i] = 0.0;
+    for (int i = 0; i <= na; i++)
+        for (int j = 0; j <= nb; j++) out[i + j] = out[i + j] + a[i] * b[j];
+}
+
+int five_point(const double* x1, const double* x2, double* models)
+{
+    // epipolar constraint rows for x2^T E x1 = 0, E row-major
+    double Q[5 * 9];
+    for (int i = 0; i < 5; i++) {
+        double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        double* q = Q + 9 * i;
+        q[0] = u2 * u1; q[1] = u2 * v1; q[2] = u2;
+        q[3] = v2 * u1; q[4] = v2 * v1; q[5] = v2;
+        q[6] = u1;      q[7] = v1;      q[8] = 1.0;
+    }
+    double N[4 * 9];  // X, Y, Z, W
+    if (!null_space_9(Q, 5, N)) return 0;
+
+    // e[r][c] = polynomial (x,y,z,1) of entry (r,c) of E = xX + yY + zZ + W
+    double e[3][3][4];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            for (int k = 0; k < 4; k++) e[r][c][k] = N[k * 9 + r * 3 + c];
+
+    double A[10][20];
+    // EE^T (symmetric), trace, Lambda = EE^T - 0.5 tr I
+    double L[3][3][10];
+    for (int i = 0; i < 3; i++)
+        for (int j = i; j < 3; j++) {
+            double t0[10], t1[10], t2[10];
+            mul11(e[i][0], e[j][0], t0);
+            mul11(e[i][1], e[j][1], t1);
+            mul11(e[i][2], e[j][2], t2);
+            for (int m = 0; m < 10; m++) L[i][j][m] = (t0[m] + t1[m]) + t2[m];
+        }
+    for (int m = 0; m < 10; m++) {
+        double tr = (L[0][0][m] + L[1][1][m]) + L[2][2][m];
+        double h = 0.5 * tr;
+        L[0][0][m] = L[0][0][m] - h;
+        L[1][1][m] = L[1][1][m] - h;
+        L[2][2][m] = L[2][2][m] - h;
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < i; j++)
+            for (int m = 0; m < 10; m++) L[i][j][m] = L[j][i][m];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double t0[20], t1[20], t2[20];
+            mul21(L[i][0], e[0][j], t0);
+            mul21(L[i][1], e[1][j], t1);
+            mul21(L[i][2], e[2][j], t2);
+            for (int m = 0; m < 20; m++) A[i * 3 + j][m] = (t0[m] + t1[m]) + t2[m];
+        }
+    {
+        double a[10], b[10], d0[10], d1[10], d2[10];
+        mul11(e[1][1], e[2][2], a); mul11(e[1][2], e[2][1], b);
+        for (int m = 0; m < 10; m++) d0[m] = a[m] - b[m];
+        mul11(e[1][0], e[2][2], a); mul11(e[1][2], e[2][0], b);
+        for (int m = 0; m < 10; m++) d1[m] = a[m] - b[m];
+        mul11(e[1][0], e[2][1], a); mul11(e[1][1], e[2][0], b);
+        for (int m = 0; m < 10; m++) d2[m] = a[m] - b[m];
+        double t0[20], t1[20], t2[20];
+        mul21(d0, e[0][0], t0);
+        mul21(d1, e[0][1], t1);
+        mul21(d2, e[0][2], t2);
+        for (int m = 0; m < 20; m++) A[9][m] = (t0[m] - t1[m]) + t2[m];
+    }
+
+    // Gauss-Jordan on the 10 leading columns, partial pivoting (first max)
+    for (int p = 0; p < 10; p++) {
+        int bi = p;
+        double best = -1.0;
+        for (int i = p; i < 10; i++) {
+            double v = std::fabs(A[i][p]);
+            if (v > best) { best = v; bi = i; }
+        }
+        if (!(best > 0.0)) return 0;
+        if (bi != p)
+            for (int j = 0; j < 20; j++) std::swap(A[p][j], A[bi][j]);
+        double piv = A[p][p];
+        for (int j = p + 1; j < 20; j++) A[p][j] = A[p][j] / piv;
+        A[p][p] = 1.0;
+        for (int i = 0; i < 10; i++) {
+            if (i == p) continue;
+            double f = A[i][p];
+            for (int j = p + 1; j < 20; j++) A[i][j] = A[i][j] - f * A[p][j];
+            A[i][p] = 0.0;
+        }
+    }
+
+    // rows e..j = 4..9; B(z) rows: e - z f, g - z h, i - z j
+    // B[r][0], B[r][1]: degree 3 in z (coefficient of x, of y); B[r][2]: degree 4
+    double B[3][3][5];
+    for (int r = 0; r < 3; r++) {
+        const double* hi = A[4 + 2 * r];  // has the extra factor z in its leading monomial
+        const double* lo = A[5 + 2 * r];
+        for (int v = 0; v < 2; v++) {
+            int c0 = 10 + 3 * v;  // columns [v z^2, v z, v]
+            B[r][v][0] = hi[c0 + 2];
+            B[r][v][1] = hi[c0 + 1] - lo[c0 + 2];
+            B[r][v][2] = hi[c0 + 0] - lo[c0 + 1];
+            B[r][v][3] = -lo[c0 + 0];
+            B[r][v][4] = 0.0;
+        }
+        // columns 16..19 = [z^3, z^2, z, 1]
+        B[r][2][0] = hi[19];
+        B[r][2][1] = hi[18] - lo[19];
+        B[r][2][2] = hi[17] - lo[18];
+        B[r][2][3] = hi[16] - lo[17];
+        B[r][2][4] = -lo[16];
+    }
+    // det B(z), degree 10
+    double c[11];
+    {
+        double p1[8], p2[8], m0[8], m1[8], m2[7], t0[11], t1[11], t2[11];
+        pmul(B[1][1], 3, B[2][2], 4, p1); pmul(B[1][2], 4, B[2][1], 3, p2);
+        for (int i = 0; i < 8; i++) m0[i] = p1[i] - p2[i];
+        pmul(B[1][0], 3, B[2][2], 4, p1); pmul(B[1][2], 4, B[2][0], 3, p2);
+        for (int i = 0; i < 8; i++) m1[i] = p1[i] - p2[i];
+        pmul(B[1][0], 3, B[2][1], 3, p1); pmul(B[1][1], 3, B[2][0], 3, p2);
+        for (int i = 0; i < 7; i++) m2[i] = p1[i] - p2[i];
+        pmul(B[0][0], 3, m0, 7, t0);
+        pmul(B[0][1], 3, m1, 7, t1);
+        pmul(B[0][2], 4, m2, 6, t2);
+        for (int i = 0; i < 11; i++) c[i] = (t0[i] - t1[i]) + t2[i];
+    }
+    double roots[10];
+    int nr = real_roots(c, 10, roots);
+    int count = 0;
+    for (int k = 0; k < nr; k++) {
+        double z = roots[k];
+        double b[3][3];
+        for (int r = 0; r < 3; r++) {
+            b[r][0] = horner(B[r][0], 3, z);
+            b[r][1] = horner(B[r][1], 3, z);
+            b[r][2] = horner(B[r][2], 4, z);
+        }
+        // null vector of b by the row-pair cross product with the largest |n_z|
+        double bestn[3] = {0, 0, 0};
+        double bestz = -1.0;
+        const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+        for (int q = 0; q < 3; q++) {
+            const double* r0 = b[pr[q][0]];
+            const double* r1 = b[pr[q][1]];
+            double nx = r0[1] * r1[2] - r0[2] * r1[1];
+            double ny = r0[2] * r1[0] - r0[0] * r1[2];
+            double nz = r0[0] * r1[1] - r0[1] * r1[0];
+            double az = std::fabs(nz);
+            if (az > bestz) { bestz = az; bestn[0] = nx; bestn[1] = ny; bestn[2] = nz; }
+        }
+        double nn = std::sqrt((bestn[0] * bestn[0] + bestn[1] * bestn[1]) + bestn[2] * bestn[2]);
+        if (!(nn > 0.0) || !(bestz / nn >= 1e-10)) continue;
+        double x = bestn[0] / bestn[2];
+        double y = bestn[1] / bestn[2];
+        double E[9];
+        double s = 0.0;
+        for (int i = 0; i < 9; i++) {
+            E[i] = ((x * N[i] + y * N[9 + i]) + z * N[18 + i]) + N[27 + i];
+            s = s + E[i] * E[i];
+        }
+        double nrm = std::sqrt(s);
+        if (!(nrm > 0.0) || !std::isfinite(nrm)) continue;
+        for (int i = 0; i < 9; i++) models[count * 9 + i] = E[i] / nrm;
+        count++;
+    }
+    return count;
+}
+
+// -------------------------------------------------------- seven-point F ----
+
+int seven_point(const float* m1, const float* m2, double* models)
+{
+    double Q[7 * 9];
+    for (int i = 0; i < 7; i++) {
+        double x0 = m1[2 * i], y0 = m1[2 * i + 1], x1 = m2[2 * i], y1 = m2[2 * i + 1];
+        double* q = Q + 9 * i;
+        q[0] = x1 * x0; q[1] = x1 * y0; q[2] = x1;
+        q[3] = y1 * x0; q[4] = y1 * y0; q[5] = y1;
+        q[6] = x0;      q[7] = y0;      q[8] = 1.0;
+    }
+    double N[2 * 9];
+    if (!null_space_9(Q, 7, N)) return 0;
+    double f1[9], f2[9];
+    for (int i = 0; i < 9; i++) { f2[i] = N[9 + i]; f1[i] = N[i] - f2[i]; }
+    // det(lambda f1 + f2) = c3 l^3 + c2 l^2 + c1 l + c0 with F = l*(N0-N1) + N1
+    // entries are degree-1 polynomials in lambda: p[i] = {f2[i], f1[i]}
+    double p[9][2];
+    for (int i = 0; i < 9; i++) { p[i][0] = f2[i]; p[i][1] = f1[i]; }
+    double a[3], b[3], m0[3], mm1[3], mm2[3], t0[4], t1[4], t2[4], c[4];
+    pmul(p[4], 1, p[8], 1, a); pmul(p[5], 1, p[7], 1, b);
+    for (int i = 0; i < 3; i++) m0[i] = a[i] - b[i];
+    pmul(p[3], 1, p[8], 1, a); pmul(p[5], 1, p[6], 1, b);
+    for (int i = 0; i < 3; i++) mm1[i] = a[i] - b[i];
+    pmul(p[3], 1, p[7], 1, a); pmul(p[4], 1, p[6], 1, b);
+    for (int i = 0; i < 3; i++) mm2[i] = a[i] - b[i];
+    pmul(p[0], 1, m0, 2, t0);
+    pmul(p[1], 1, mm1, 2, t1);
+    pmul(p[2], 1, mm2, 2, t2);
+    for (int i = 0; i < 4; i++) c[i] = (t0[i] - t1[i]) + t2[i];
+    double roots[3];
+    int nr = real_roots(c, 3, roots);
+    int count = 0;
+    for (int k = 0; k < nr; k++) {
+        double lambda = roots[k], mu = 1.0;
+        double s = f1[8] * lambda + f2[8];
+        double* F = models + 9 * count;
+        if (std::fabs(s) > DBL_EPSILON) {
+            mu = 1.0 / s;
+            lambda = lambda * mu;
+            F[8] = 1.0;
+        } else {
+            F[8] = 0.0;
+        }
+        for (int i = 0; i < 8; i++) F[i] = f1[i] * lambda + f2[i] * mu;
+        count++;
+    }
+    return count;
+}
+
+bool have_collinear(const float* pts, const int* idx, int count)
+{
+    int i = count - 1;
+    const float* pi = pts + 2 * idx[i];
+    for (int j = 0; j < i; j++) {
+        const float* pj = pts + 2 * idx[j];
+        double dx1 = pj[0] - pi[0];
+        double dy1 = pj[1] - pi[1];
+        for (int k = 0; k < j; k++) {
+            const float* pk = pts + 2 * idx[k];
+            double dx2 = pk[0] - pi[0];
+            double dy2 = pk[1] - pi[1];
+            if (std::fabs(dx2 * dy1 - dy2 * dx1) <=
+                FLT_EPSILON * (std::fabs(dx1) + std::fabs(dy1) + std::fabs(dx2) + std::fabs(dy2)))
+                return true;
+        }
+    }
+    return false;
+}
+
+// getSubset: m distinct uniform draws; optional subset check redraws the
+// whole subset (at most max_attempts times).
+bool get_subset(CvRng& rng, int count, int m, int* idx, const float* p1, const float* p2,
+                int max_attempts)
+{
+    int iters = 0;
+    int i = 0;
+    for (; iters < max_attempts; iters++) {
+        for (i = 0; i < m && iters < max_attempts;) {
+            int v;
+            for (;;) {
+                v = idx[i] = rng.uniform(0, count);
+                int j = 0;
+                for (; j < i; j++)
+                    if (v == idx[j]) break;
+                if (j == i) break;
+            }
+            i++;
+        }
+        if (i == m && p1 && (have_collinear(p1, idx, m) || have_collinear(p2, idx, m))) continue;
+        break;
+    }
+    return i == m && iters < max_attempts;
+}
+
+int cv_round(double v) { return (int)std::nearbyint(v); }
+
+int update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = std::max(p, 0.); p = std::min(p, 1.);
+    ep = std::max(ep, 0.); ep = std::min(ep, 1.);
+    double num = std::max(1. - p, DBL_MIN);
+    double denom = 1. - std::pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = std::log(num);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : cv_round(num / denom);
+}
+
+void sampson(const double* E, const double* x1, const double* x2, int n, float* err)
+{
+    for (int i = 0; i < n; i++) {
+        double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        double Ex1_0 = (E[0] * u1 + E[1] * v1) + E[2];
+        double Ex1_1 = (E[3] * u1 + E[4] * v1) + E[5];
+        double Ex1_2 = (E[6] * u1 + E[7] * v1) + E[8];
+        double Etx2_0 = (E[0] * u2 + E[3] * v2) + E[6];
+        double Etx2_1 = (E[1] * u2 + E[4] * v2) + E[7];
+        double s = (u2 * Ex1_0 + v2 * Ex1_1) + Ex1_2;
+        double a = Ex1_0 * Ex1_0;
+        double b = Ex1_1 * Ex1_1;
+        double c = Etx2_0 * Etx2_0;
+        double d = Etx2_1 * Etx2_1;
+        err[i] = (float)(s * s / (((a + b) + c) + d));
+    }
+}
+
+void symepi(const double* F, const float* m1, const float* m2, int n, float* err)
+{
+    for (int i = 0; i < n; i++) {
+        double x1 = m1[2 * i], y1 = m1[2 * i + 1], x2 = m2[2 * i], y2 = m2[2 * i + 1];
+        double a = (F[0] * x1 + F[1] * y1) + F[2];
+        double b = (F[3] * x1 + F[4] * y1) + F[5];
+        double c = (F[6] * x1 + F[7] * y1) + F[8];
+        double s2 = 1. / (a * a + b * b);
+        double d2 = (x2 * a + y2 * b) + c;
+        a = (F[0] * x2 + F[3] * y2) + F[6];
+        b = (F[1] * x2 + F[4] * y2) + F[7];
+        c = (F[2] * x2 + F[5] * y2) + F[8];
+        double s1 = 1. / (a * a + b * b);
+        double d1 = (x1 * a + y1 * b) + c;
+        err[i] = (float)std::max(d1 * d1 * s1, d2 * d2 * s2);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int oracle_knn_match(const float* query, int nq, size_t qstep, const float* train, int nt,
+                     size_t tstep, int dim, int k, oracle_dmatch* out, int32_t* counts,
+                     int nthreads)
+{
+    if (nq < 0 || nt < 0 || dim <= 0 || k <= 0) return -1;
+    if (nq == 0) return 0;
+    if (nthreads < 1) nthreads = 1;
+    nthreads = std::min(nthreads, nq);
+    if (nthreads == 1) {
+        knn_rows(query, 0, nq, qstep, train, nt, tstep, dim, k, out, counts);
+        return 0;
+    }
+    std::vector<std::thread> th;
+    int per = (nq + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        int q0 = t * per, q1 = std::min(nq, q0 + per);
+        if (q0 >= q1) break;
+        th.emplace_back(knn_rows, query, q0, q1, qstep, train, nt, tstep, dim, k, out, counts);
+    }
+    for (auto& t : th) t.join();
+    return 0;
+}
+
+int oracle_ratio_test(const oracle_dmatch* matches, const int32_t* counts, int nq, int k,
+                      double ratio, int32_t* keep_rows)
+{
+    int n = 0;
+    for (int r = 0; r < nq; r++) {
+        if (counts[r] < 2) continue;
+        const oracle_dmatch* m = matches + (size_t)r * k;
+        if ((double)m[0].distance < ratio * (double)m[1].distance) keep_rows[n++] = r;
+    }
+    return n;
+}
+
+void oracle_rng_next(uint64_t seed, int n, uint32_t* out)
+{
+    CvRng rng(seed);
+    for (int i = 0; i < n; i++) out[i] = rng.next();
+}
+
+void oracle_rng_uniform(uint64_t seed, int a, int b, int n, int32_t* out)
+{
+    CvRng rng(seed);
+    for (int i = 0; i < n; i++) out[i] = rng.uniform(a, b);
+}
+
+int oracle_sample_table(int count, int m, int n_iters, int32_t* out)
+{
+    if (count < m || m <= 0) return -1;
+    CvRng rng((uint64_t)-1);
+    for (int it = 0; it < n_iters; it++)
+        if (!get_subset(rng, count, m, out + (size_t)it * m, nullptr, nullptr, 10000)) return -1;
+    return 0;
+}
+
+int oracle_sample_table_f(int count, const float* pts1, const float* pts2, int n_iters,
+                          int32_t* out)
+{
+    if (count < 7) return -1;
+    CvRng rng((uint64_t)-1);
+    for (int it = 0; it < n_iters; it++)
+        if (!get_subset(rng, count, 7, out + (size_t)it * 7, pts1, pts2, 10000)) return it;
+    return n_iters;
+}
+
+int oracle_ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    return update_num_iters(p, ep, model_points, max_iters);
+}
+
+int oracle_five_point(const double* x1, const double* x2, double* models)
+{
+    return five_point(x1, x2, models);
+}
+
+int oracle_seven_point(const float* x1, const float* x2, double* models)
+{
+    return seven_point(x1, x2, models);
+}
+
+void oracle_sampson_errors(const double* E, const double* x1, const double* x2, int n, float* err)
+{
+    sampson(E, x1, x2, n, err);
+}
+
+void oracle_symepi_errors(const double* F, const float* x1, const float* x2, int n, float* err)
+{
+    symepi(F, x1, x2, n, err);
+}
+
+double oracle_normalize_points(const double* pts_px, int n, const double* K, double threshold_px,
+                               double* out)
+{
+    double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    for (int i = 0; i < n; i++) {
+        out[2 * i] = (pts_px[2 * i] - cx) / fx;
+        out[2 * i + 1] = (pts_px[2 * i + 1] - cy) / fy;
+    }
+    return threshold_px / ((fx + fy) / 2);
+}
+
+int oracle_ransac(int model_kind, const double* pts1, const double* pts2, int n, const double* K,
+                  double prob, double threshold_px, int max_iters, int fixed_count,
+                  const int32_t* sample_table, uint8_t* mask, double* model_out,
+                  int32_t* n_inliers, int32_t* iters_used, int32_t* hyp_counts)
+{
+    if (model_kind != 0 && model_kind != 1) return -1;
+    if (n < 0 || !(prob > 0 && prob < 1)) return -1;
+    const int m = model_kind == 0 ? 5 : 7;
+    if (n_inliers) *n_inliers = 0;
+    if (iters_used) *iters_used = 0;
+    if (n < m) return 0;
+
+    std::vector<double> x1, x2;
+    std::vector<float> f1, f2;
+    double thr = threshold_px;
+    if (model_kind == 0) {
+        x1.resize(2 * (size_t)n);
+        x2.resize(2 * (size_t)n);
+        thr = oracle_normalize_points(pts1, n, K, threshold_px, x1.data());
+        oracle_normalize_points(pts2, n, K, threshold_px, x2.data());
+    } else {
+        f1.resize(2 * (size_t)n);
+        f2.resize(2 * (size_t)n);
+        for (int i = 0; i < 2 * n; i++) { f1[i] = (float)pts1[i]; f2[i] = (float)pts2[i]; }
+    }
+    const float t = (float)(thr * thr);
+
+    auto solve = [&](const int* idx, double* models) -> int {
+        if (model_kind == 0) {
+            double a[10], b[10];
+            for (int i = 0; i < 5; i++) {
+                a[2 * i] = x1[2 * idx[i]]; a[2 * i + 1] = x1[2 * idx[i] + 1];
+                b[2 * i] = x2[2 * idx[i]]; b[2 * i + 1] = x2[2 * idx[i] + 1];
+            }
+            return five_point(a, b, models);
+        }
+        float a[14], b[14];
+        for (int i = 0; i < 7; i++) {
+            a[2 * i] = f1[2 * idx[i]]; a[2 * i + 1] = f1[2 * idx[i] + 1];
+            b[2 * i] = f2[2 * idx[i]]; b[2 * i + 1] = f2[2 * idx[i] + 1];
+        }
+        return seven_point(a, b, models);
+    };
+    std::vector<float> err(n);
+    auto errors = [&](const double* M) {
+        if (model_kind == 0) sampson(M, x1.data(), x2.data(), n, err.data());
+        else symepi(M, f1.data(), f2.data(), n, err.data());
+    };
+
+    double models[10 * 9];
+    if (n == m) {
+        int idx[7];
+        for (int i = 0; i < m; i++) idx[i] = i;
+        int nm = solve(idx, models);
+        if (nm <= 0) return 0;
+        // OpenCV returns every candidate stacked; this interface reports the first
+        std::memcpy(model_out, models, 9 * sizeof(double));
+        std::memset(mask, 1, n);
+        if (n_inliers) *n_inliers = n;
+        return 1;
+    }
+
+    CvRng rng((uint64_t)-1);
+    int niters = fixed_count > 0 ? fixed_count : std::max(max_iters, 1);
+    int best = 0;
+    std::vector<uint8_t> cur(n);
+    double best_model[9] = {0};
+    int iter = 0;
+    for (; iter < niters; iter++) {
+        int idx[7];
+        if (sample_table) {
+            for (int i = 0; i < m; i++) idx[i] = sample_table[(size_t)iter * m + i];
+        } else {
+            bool found = get_subset(rng, n, m, idx, model_kind == 1 ? f1.data() : nullptr,
+                                    model_kind == 1 ? f2.data() : nullptr, 10000);
+            if (!found) {
+                if (iter == 0) return 0;
+                break;
+            }
+        }
+        if (hyp_counts)
+            for (int q = 0; q < 10; q++) hyp_counts[(size_t)iter * 10 + q] = -1;
+        int nm = solve(idx, models);
+        if (nm <= 0) continue;
+        for (int q = 0; q < nm; q++) {
+            errors(models + 9 * q);
+            int good = 0;
+            for (int i = 0; i < n; i++) {
+                int f = err[i] <= t;
+                cur[i] = (uint8_t)f;
+                good += f;
+            }
+            if (hyp_counts) hyp_counts[(size_t)iter * 10 + q] = good;
+            if (good > std::max(best, m - 1)) {
+                std::memcpy(mask, cur.data(), n);
+                std::memcpy(best_model, models + 9 * q, sizeof(best_model));
+                best = good;
+                if (fixed_count <= 0)
+                    niters = update_num_iters(prob, (double)(n - good) / n, m, niters);
+            }
+        }
+    }
+    if (iters_used) *iters_used = iter;
+    if (best > 0) {
+        std::memcpy(model_out, best_model, sizeof(best_model));
+        if (n_inliers) *n_inliers = best;
+        return 1;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+/*
+ * CPU ORACLE — TEST INFRASTRUCTURE ONLY.
+ *
+ * A dependency-free CPU restatement of the semantics behind the two library
+ * calls on the reference's matching path:
+ *     matcher->knnMatch(descL, descR, matches, 2)      /root/reference/main.cpp:184
+ *     ratio test in double                              /root/reference/main.cpp:189-197
+ *     findEssentialMat(..., FM_RANSAC, 0.99, 1.0, mask) /root/reference/main.cpp:224
+ *
+ * The arithmetic of those calls lives in OpenCV 4.5.5 (pinned only by
+ * /root/reference/README.md:5), which is NOT vendored in the reference and is
+ * not installed here.  The reference holds no tests, fixtures or golden
+ * vectors for this path, so:  PARITY UNPINNED.  This file restates the
+ * published algorithms (brute-force L2 k-NN with OpenCV's insertion order,
+ * cv::RNG, the RANSAC point-set registrator loop, Nister's five-point
+ * solver, Sampson error) and is pinned only by known-answer tests that can be
+ * derived without OpenCV (tests/test_oracle_kat.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The shipped GPU path never links or calls it.
+ */
+#ifndef SFM_ORACLE_H
+#define SFM_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Layout-identical to cv::DMatch (queryIdx, trainIdx, imgIdx, distance). */
+typedef struct {
+    int32_t queryIdx;
+    int32_t trainIdx;
+    int32_t imgIdx;
+    float distance;
+} oracle_dmatch;
+
+/* Brute-force k-NN, NORM_L2, float32 rows with byte strides.  Writes
+ * nq*k records (unused slots: trainIdx=-1) and nq neighbour counts
+ * (=min(k,nt)).  Returns 0, or -1 on bad arguments. */
+int oracle_knn_match(const float* query, int nq, size_t qstep_bytes,
+                     const float* train, int nt, size_t tstep_bytes,
+                     int dim, int k, oracle_dmatch* out, int32_t* counts,
+                     int nthreads);
+
+/* Ratio test of main.cpp:189-197: keep row r iff
+ * (double)m[r][0].distance < ratio * (double)m[r][1].distance.  Rows with
+ * fewer than 2 neighbours are skipped (the reference reads m[r][1]
+ * unconditionally: undefined behaviour there).  Returns survivor count and
+ * writes survivor row numbers ascending. */
+int oracle_ratio_test(const oracle_dmatch* matches, const int32_t* counts,
+                      int nq, int k, double ratio, int32_t* keep_rows);
+
+/* cv::RNG stream from a given 64-bit seed. */
+void oracle_rng_next(uint64_t seed, int n, uint32_t* out);
+void oracle_rng_uniform(uint64_t seed, int a, int b, int n, int32_t* out);
+
+/* Sample table of the RANSAC loop: n_iters subsets of m distinct indices in
+ * [0,count) drawn exactly as RANSACPointSetRegistrator::getSubset does with
+ * RNG(-1) (no subset check: the essential-matrix callback accepts every
+ * subset).  Returns 0, -1 if count < m. */
+int oracle_sample_table(int count, int m, int n_iters, int32_t* out);
+
+/* Same with the fundamental-matrix subset check (collinearity in either
+ * image, float coordinates); pts are n x 2 float32 pixel coordinates.
+ * Returns number of subsets produced (may stop early when 10000 attempts
+ * fail). */
+int oracle_sample_table_f(int count, const float* pts1, const float* pts2,
+                          int n_iters, int32_t* out);
+
+int oracle_ransac_update_num_iters(double p, double ep, int model_points,
+                                   int max_iters);
+
+/* Five-point solver on 5 normalised correspondences (x1: 5x2, x2: 5x2).
+ * Writes up to 10 row-major 3x3 models with unit Frobenius norm, in
+ * ascending order of the real root z.  Returns the model count. */
+int oracle_five_point(const double* x1, const double* x2, double* models);
+
+/* Seven-point solver on 7 float32 pixel correspondences.  Up to 3 models,
+ * F33 = 1 when possible.  Returns the model count. */
+int oracle_seven_point(const float* x1, const float* x2, double* models);
+
+/* Sampson error of model E at n normalised correspondences, double
+ * arithmetic cast to float (no fused multiply-add). */
+void oracle_sampson_errors(const double* E, const double* x1, const double* x2,
+                           int n, float* err);
+
+/* Fundamental-matrix error: max of the two squared point-to-epipolar-line
+ * distances, float32 pixel points, double arithmetic cast to float. */
+void oracle_symepi_errors(const double* F, const float* x1, const float* x2,
+                          int n, float* err);
+
+/* Normalisation done by findEssentialMat before RANSAC:
+ * x=(u-cx)/fx, y=(v-cy)/fy ; returns threshold/((fx+fy)/2). */
+double oracle_normalize_points(const double* pts_px, int n, const double* K,
+                               double threshold_px, double* out);
+
+/*
+ * RANSAC essential matrix (model_kind=0, m=5, Sampson) or fundamental matrix
+ * (model_kind=1, m=7, symmetric epipolar).
+ *   pts1/pts2     n x 2 double pixel coordinates
+ *   K             3x3 row-major (ignored for model_kind=1)
+ *   fixed_count   0: OpenCV-adaptive loop (max_iters cap, niters shrinks);
+ *                 >0: evaluate exactly that many hypotheses, no early stop
+ *   sample_table  optional fixed_count*m (or max_iters*m) indices; NULL =>
+ *                 generated from RNG(-1) like OpenCV
+ *   mask          n bytes; untouched when the call fails (n < m)
+ *   hyp_counts    optional [n_hyp][10] inlier counts (-1 = no such model),
+ *                 filled for the hypotheses actually evaluated
+ * Returns 1 on success, 0 on failure (OpenCV's `false`), -1 bad arguments.
+ */
+int oracle_ransac(int model_kind, const double* pts1, const double* pts2, int n,
+                  const double* K, double prob, double threshold_px,
+                  int max_iters, int fixed_count, const int32_t* sample_table,
+                  uint8_t* mask, double* model_out, int32_t* n_inliers,
+                  int32_t* iters_used, int32_t* hyp_counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+"""Seeded synthetic inputs of the shapes the matching path sees.
+
+Descriptors mimic what cv::SIFT::detectAndCompute hands to the matcher at
+/root/reference/main.cpp:143: N x 128 float32 rows whose values are integers in
+0..255 with an L2 norm near 512.  Two-view geometry uses the intrinsics
+hard-coded at /root/reference/main.cpp:103-105 and the depth range of
+/root/reference/cams_1/00000000_cam.txt:12.
+"""
+import numpy as np
+
+# main.cpp:103-105
+REF_K = np.array([[2892.33, 0.0, 823.205],
+                  [0.0, 2883.18, 619.071],
+                  [0.0, 0.0, 1.0]], dtype=np.float64)
+IMG_W, IMG_H = 1600, 1200
+
+
+def sift_like(n, seed):
+    """n x 128 float32, integer-valued 0..255, SIFT-style normalisation."""
+    rng = np.random.default_rng(seed)
+    v = rng.exponential(1.0, size=(n, 128))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v = np.minimum(v, 0.2)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v = np.rint(v * 512.0)
+    return np.clip(v, 0, 255).astype(np.float32)
+
+
+def uniform_u8(n, seed, dim=128):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, size=(n, dim)).astype(np.float32)
+
+
+def planted_pair(n_query, n_train, seed_q, seed_t, seed_perm, frac=0.4, sigma=6.0):
+    """Query/train descriptor sets where `frac` of the query rows have a noisy
+    copy at a permuted position in the train set.  Returns (Q, T, planted)
+    with planted[i] = train row of query i's copy, or -1."""
+    Q = sift_like(n_query, seed_q)
+    T = sift_like(n_train, seed_t)
+    rng = np.random.default_rng(seed_perm)
+    n_pl = int(min(n_query, n_train) * frac)
+    q_rows = rng.permutation(n_query)[:n_pl]
+    t_rows = rng.permutation(n_train)[:n_pl]
+    noise = np.rint(rng.normal(0.0, sigma, size=(n_pl, 128)))
+    T[t_rows] = np.clip(Q[q_rows] + noise, 0, 255).astype(np.float32)
+    planted = np.full(n_query, -1, dtype=np.int64)
+    planted[q_rows] = t_rows
+    return Q, T, planted
+
+
+def _rot(axis, ang):
+    axis = axis / np.linalg.norm(axis)
+    kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * kx + (1 - np.cos(ang)) * (kx @ kx)
+
+
+def two_view(n, seed, inlier_frac=0.9, noise_px=0.5, K=REF_K):
+    """n correspondences in pixels (float32 precision, stored float64 like the
+    Point2f -> Point2d widening at main.cpp:194-195).  Returns
+    (pts1, pts2, is_inlier, E_true) with E_true for normalised coordinates."""
+    rng = np.random.default_rng(seed)
+    n_in = int(round(n * inlier_frac))
+    Kinv = np.linalg.inv(K)
+    # sample pixels in image 1 and depths, back-project
+    px = np.stack([rng.uniform(0, IMG_W, n_in), rng.uniform(0, IMG_H, n_in), np.ones(n_in)], 1)
+    depth = rng.uniform(425.0, 935.0, n_in)
+    X = (px @ Kinv.T) * depth[:, None]
+    R = _rot(rng.normal(size=3), np.deg2rad(rng.uniform(1.0, 5.0)))
+    t = rng.normal(size=3)
+    t[2] *= 0.2
+    t = t / np.linalg.norm(t) * 25.0
+    X2 = X @ R.T + t
+    p2 = X2 @ K.T
+    p2 = p2[:, :2] / p2[:, 2:]
+    p1 = px[:, :2] + rng.normal(0, noise_px, (n_in, 2))
+    p2 = p2 + rng.normal(0, noise_px, (n_in, 2))
+    n_out = n - n_in
+    o1 = np.stack([rng.uniform(0, IMG_W, n_out), rng.uniform(0, IMG_H, n_out)], 1)
+    o2 = np.stack([rng.uniform(0, IMG_W, n_out), rng.uniform(0, IMG_H, n_out)], 1)
+    pts1 = np.concatenate([p1, o1], 0)
+    pts2 = np.concatenate([p2, o2], 0)
+    is_in = np.concatenate([np.ones(n_in, bool), np.zeros(n_out, bool)])
+    perm = rng.permutation(n)
+    pts1, pts2, is_in = pts1[perm], pts2[perm], is_in[perm]
+    pts1 = pts1.astype(np.float32).astype(np.float64)
+    pts2 = pts2.astype(np.float32).astype(np.float64)
+    tn = t / np.linalg.norm(t)
+    tx = np.array([[0, -tn[2], tn[1]], [tn[2], 0, -tn[0]], [-tn[1], tn[0], 0]])
+    E = tx @ R
+    E /= np.linalg.norm(E)
+    return pts1, pts2, is_in, E
+
+
+def keypoints_for_pair(n_query, n_train, planted, seed, noise_px=0.5, K=REF_K):
+    """Keypoint coordinates (float32 n x 2) for both images of a planted pair:
+    planted rows are projections of common 3-D points, the rest are random."""
+    rng = np.random.default_rng(seed)
+    kq = np.stack([rng.uniform(0, IMG_W, n_query), rng.uniform(0, IMG_H, n_query)], 1)
+    kt = np.stack([rng.uniform(0, IMG_W, n_train), rng.uniform(0, IMG_H, n_train)], 1)
+    rows = np.nonzero(planted >= 0)[0]
+    Kinv = np.linalg.inv(K)
+    px = np.concatenate([kq[rows], np.ones((len(rows), 1))], 1)
+    depth = rng.uniform(425.0, 935.0, len(rows))
+    X = (px @ Kinv.T) * depth[:, None]
+    R = _rot(rng.normal(size=3), np.deg2rad(rng.uniform(1.0, 5.0)))
+    t = rng.normal(size=3)
+    t[2] *= 0.2
+    t = t / np.linalg.norm(t) * 25.0
+    p2 = (X @ R.T + t) @ K.T
+    p2 = p2[:, :2] / p2[:, 2:]
+    kq[rows] += rng.normal(0, noise_px, (len(rows), 2))
+    kt[planted[rows]] = p2 + rng.normal(0, noise_px, (len(rows), 2))
+    return kq.astype(np.float32), kt.astype(np.float32)
