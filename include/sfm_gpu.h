@@ -1,0 +1,211 @@
+/*
+ * sfm_gpu.h — C ABI of the MI355X (gfx950) matching path.
+ *
+ * The reference (Suxilan/SFM) has no plugin or FFI layer; its matching hot
+ * path is two C++ library calls inside match() (/root/reference/main.cpp:159).
+ * Each entry point below names the reference line(s) whose work it replaces.
+ * All pointers are plain host or device addresses, all sizes are plain
+ * integers, nothing throws: every call returns SFM_GPU_OK (0) or a negative
+ * SFM_GPU_ERR_* code, and sfm_gpu_last_error_string() explains the last
+ * failure on that context.  The caller owns every buffer it passes in; the
+ * library keeps no reference to caller memory after a call returns.
+ *
+ * Threading: a context is bound to one GPU and one HIP stream and must be used
+ * by one host thread at a time.  Calls taking host pointers are synchronous
+ * (they return when the outputs are written), like the calls they replace.
+ */
+#ifndef SFM_GPU_H
+#define SFM_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_GPU_OK 0
+#define SFM_GPU_ERR_ARG (-1)          /* null pointer, negative size, dim != 128, ...   */
+#define SFM_GPU_ERR_HIP (-2)          /* a HIP runtime call failed                       */
+#define SFM_GPU_ERR_NOT_U8 (-3)       /* a descriptor value is not an integer in 0..255  */
+#define SFM_GPU_ERR_TOO_MANY (-4)     /* n_train >= 2^18 (cv::BFMatcher asserts the same)*/
+#define SFM_GPU_ERR_UNSUPPORTED (-5)  /* k > 2, unknown dtype / model / mode             */
+#define SFM_GPU_ERR_NOMEM (-6)
+#define SFM_GPU_ERR_CAPACITY (-7)     /* a size exceeds a documented fixed maximum       */
+
+/* descriptor element types */
+#define SFM_GPU_DESC_F32 0 /* float32 holding integers 0..255 (cv::SIFT output, CV_32F) */
+#define SFM_GPU_DESC_U8 1  /* uint8 (CV_8U)                                             */
+
+/* RANSAC models */
+#define SFM_GPU_MODEL_ESSENTIAL 0   /* 5-point, Sampson error (cv::findEssentialMat)          */
+#define SFM_GPU_MODEL_FUNDAMENTAL 1 /* 7-point, symmetric epipolar (cv::findFundamentalMat)   */
+
+/* RANSAC modes */
+#define SFM_GPU_RANSAC_ADAPTIVE 0 /* OpenCV loop: max_iters cap, iteration count shrinks   */
+#define SFM_GPU_RANSAC_FIXED 1    /* evaluate exactly n_hyp hypotheses, no early stop      */
+
+/* Layout-identical to cv::DMatch: the output rows of knnMatch can be
+ * memcpy'd into std::vector<cv::DMatch>. */
+typedef struct sfm_gpu_dmatch {
+    int32_t queryIdx;
+    int32_t trainIdx;
+    int32_t imgIdx; /* always 0: one train image per call, as at main.cpp:184 */
+    float distance;
+} sfm_gpu_dmatch;
+
+typedef struct sfm_gpu_ctx sfm_gpu_ctx;
+typedef struct sfm_gpu_image sfm_gpu_image;
+
+/* ---- context --------------------------------------------------------- */
+
+/* Creates a context on GPU `device_id`.  `hip_stream` is a hipStream_t to
+ * launch on (NULL: the library creates its own stream).  Replaces nothing in
+ * the reference (which has no device); it stands where main.cpp:181 builds a
+ * matcher object per pair. */
+int sfm_gpu_create(int device_id, void* hip_stream, sfm_gpu_ctx** out);
+void sfm_gpu_destroy(sfm_gpu_ctx* ctx);
+const char* sfm_gpu_last_error_string(const sfm_gpu_ctx* ctx);
+/* Waits for everything queued on the context's stream. */
+int sfm_gpu_synchronize(sfm_gpu_ctx* ctx);
+/* Library build identification, e.g. "sfm_gpu 0.1 gfx950". */
+const char* sfm_gpu_version(void);
+
+/* ---- k-NN matching: replaces main.cpp:181-184 ------------------------- */
+
+/*
+ * matcher->knnMatch(descriptorsL, descriptorsR, matches, 2)   main.cpp:184
+ * with cv::BFMatcher(NORM_L2) semantics: for each query row the k nearest
+ * train rows by L2 distance, ascending by (distance as float32, trainIdx).
+ *
+ *   query/train   host pointers to row-major descriptors, `*_step` bytes
+ *                 between rows (cv::Mat::step), dim must be 128
+ *   dtype         SFM_GPU_DESC_F32 or SFM_GPU_DESC_U8
+ *   k             1 or 2
+ *   matches       out, n_query*k records; slots beyond counts[i] have
+ *                 trainIdx = -1
+ *   counts        out, n_query entries = min(k, n_train)  (the reference reads
+ *                 matches[i][1] unconditionally at main.cpp:192; callers should
+ *                 check counts)
+ * n_query == 0 or n_train == 0 is not an error: counts are all 0.
+ */
+int sfm_gpu_knn_match(sfm_gpu_ctx* ctx, const void* query, int n_query, size_t query_step,
+                      const void* train, int n_train, size_t train_step, int dim, int dtype,
+                      int k, sfm_gpu_dmatch* matches, int32_t* counts);
+
+/*
+ * Ratio test of main.cpp:189-197 on the output of sfm_gpu_knn_match:
+ * keeps row i iff counts[i] >= 2 and
+ *   (double)matches[i*k].distance < ratio * (double)matches[i*k+1].distance.
+ * Writes the surviving row numbers ascending into keep_rows (capacity
+ * n_query) and their number into *n_keep.  Host-side, O(n_query).
+ */
+int sfm_gpu_ratio_test(const sfm_gpu_dmatch* matches, const int32_t* counts, int n_query, int k,
+                       double ratio, int32_t* keep_rows, int32_t* n_keep);
+
+/* ---- RANSAC: replaces main.cpp:222-224 -------------------------------- */
+
+/*
+ * findEssentialMat(ptsL, ptsR, K, FM_RANSAC, prob, threshold, mask)   main.cpp:224
+ * (and main.cpp:418, bundle_adjustment.h:79 without a mask), or the
+ * findFundamentalMat(FM_RANSAC) counterpart when model = FUNDAMENTAL.
+ *
+ *   pts1, pts2    host, n x 2 doubles, pixel coordinates (Point2d)
+ *   K             host, 3x3 row-major camera matrix (ESSENTIAL only; may be
+ *                 NULL for FUNDAMENTAL)
+ *   prob          RANSAC confidence in (0,1)        (0.99 at main.cpp:224)
+ *   threshold_px  inlier threshold in pixels        (1.0 at main.cpp:224)
+ *   max_iters     iteration cap of the adaptive loop (OpenCV default 1000)
+ *   mode          SFM_GPU_RANSAC_ADAPTIVE reproduces OpenCV's sequential,
+ *                 self-shortening loop; SFM_GPU_RANSAC_FIXED scores exactly
+ *                 n_hyp hypotheses
+ *   sample_table  host, optional n_hyp x m int32 point indices (m = 5 or 7),
+ *                 FIXED mode only; NULL: the table OpenCV's RNG(-1) would draw
+ *   n_hyp         hypotheses in FIXED mode (ignored in ADAPTIVE)
+ *   mask          out, n bytes 0/1; left untouched when *ok == 0
+ *   model         out, 9 doubles row-major (E on normalised coordinates with
+ *                 unit Frobenius norm, or F on pixels with F33 = 1)
+ *   n_inliers, iters_used   out, optional
+ *   ok            out: 1 = a model was found, 0 = none (n < m, or no
+ *                 hypothesis reached m inliers) — OpenCV returns an empty Mat
+ */
+int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int n,
+                   const double* K, int model, double prob, double threshold_px, int max_iters,
+                   int mode, const int32_t* sample_table, int n_hyp, uint8_t* mask,
+                   double* model_out, int32_t* n_inliers, int32_t* iters_used, int32_t* ok);
+
+/* ---- device-resident images: the all-pairs driver --------------------- */
+
+/*
+ * Uploads and prepares one image's descriptors (and optionally its keypoint
+ * coordinates, n x 2 float32 like cv::KeyPoint::pt) once, so that exhaustive
+ * pair matching does not re-upload per pair.  Stands for the per-image
+ * cv::Mat descriptors[i] / keypoints[i] of main.cpp:175-178.
+ * `desc_on_device` != 0 means `desc` and `keypoints_xy` are device pointers.
+ */
+int sfm_gpu_image_create(sfm_gpu_ctx* ctx, const void* desc, int n, size_t step, int dim,
+                         int dtype, const float* keypoints_xy, int desc_on_device,
+                         sfm_gpu_image** out);
+void sfm_gpu_image_destroy(sfm_gpu_ctx* ctx, sfm_gpu_image* img);
+int sfm_gpu_image_rows(const sfm_gpu_image* img);
+
+/*
+ * knnMatch (main.cpp:184) between two prepared images.  matches/counts are
+ * host pointers, or device pointers when out_on_device != 0 (then the call
+ * only enqueues work on the context's stream).
+ */
+int sfm_gpu_knn_match_images(sfm_gpu_ctx* ctx, const sfm_gpu_image* query,
+                             const sfm_gpu_image* train, int k, sfm_gpu_dmatch* matches,
+                             int32_t* counts, int out_on_device);
+
+/* Parameters of one match() iteration (main.cpp:181-231). */
+typedef struct sfm_gpu_match_params {
+    double ratio;        /* 0.7 at main.cpp:189                                */
+    int32_t model;       /* SFM_GPU_MODEL_*                                    */
+    int32_t mode;        /* SFM_GPU_RANSAC_*                                   */
+    double K[9];         /* camera matrix of the query image (main.cpp:179)    */
+    double prob;         /* 0.99                                               */
+    double threshold_px; /* 1.0                                                */
+    int32_t max_iters;   /* 1000                                               */
+    int32_t n_hyp;       /* FIXED mode hypothesis count                        */
+} sfm_gpu_match_params;
+
+/*
+ * The body of the reference's pair loop (main.cpp:175-231, 267) for a list of
+ * image pairs: kNN(k=2) -> ratio test -> RANSAC mask -> inlier matches.
+ *
+ *   images        array of prepared images
+ *   pairs         host, n_pairs x 2 int32 (query image, train image)
+ *   n_good        out, per pair: ratio-test survivors  ("goodMatches.size()")
+ *   n_inliers     out, per pair: RANSAC inliers        ("selectMatches.size()")
+ *   inlier_matches  out, optional: n_pairs * match_capacity records; pair p's
+ *                 selectMatches occupy [p*match_capacity, +n_inliers[p])
+ *   match_capacity  records reserved per pair (>= the largest query image when
+ *                 inlier_matches != NULL)
+ * Images without keypoints can only be used with inlier_matches == NULL and
+ * mode FIXED on synthetic geometry supplied separately; normally keypoints are
+ * required.
+ */
+int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const int32_t* pairs,
+                        int n_pairs, const sfm_gpu_match_params* params, int32_t* n_good,
+                        int32_t* n_inliers, sfm_gpu_dmatch* inlier_matches,
+                        int match_capacity);
+
+/* ---- measurement support --------------------------------------------- */
+
+/*
+ * Per-kernel device time.  With profiling enabled the library brackets each
+ * launch of its named kernels with HIP events on the context's stream; the
+ * query returns accumulated milliseconds and launch count since the last
+ * reset.  Kernel names: "knn2_mfma", "prep_rows", "knn_finalize",
+ * "ratio_compact", "ransac_table", "ransac_solve", "ransac_score",
+ * "ransac_select".  Has no counterpart in the reference.
+ */
+int sfm_gpu_profile_enable(sfm_gpu_ctx* ctx, int on);
+int sfm_gpu_profile_reset(sfm_gpu_ctx* ctx);
+int sfm_gpu_profile_query(sfm_gpu_ctx* ctx, const char* kernel, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,26 @@
+/*
+ * sfm_gpu_debug.h — test hooks of libsfm_gpu.  None of these has a counterpart
+ * in the reference; they exist so that tests can pin hardware assumptions and
+ * exercise every kernel shape.
+ */
+#ifndef SFM_GPU_DEBUG_H
+#define SFM_GPU_DEBUG_H
+
+#include "sfm_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Forces the workgroup shape of the distance kernel (-1: planner decides). */
+int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* ctx, int variant);
+
+/* c[32][32] (int32) = a[32][32] * b^T with b given as [32 columns][32 k], all
+ * host pointers, through one v_mfma_i32_32x32x32_i8 loaded the way the
+ * distance kernel loads its operands. */
+int sfm_gpu_debug_mfma_probe(sfm_gpu_ctx* ctx, const int8_t* a, const int8_t* b, int32_t* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

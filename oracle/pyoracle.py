@@ -44,6 +44,8 @@ def lib():
         L.oracle_sample_table_f.restype = c.c_int
         L.oracle_ransac_update_num_iters.argtypes = [c.c_double, c.c_double, c.c_int, c.c_int]
         L.oracle_ransac_update_num_iters.restype = c.c_int
+        L.oracle_real_roots.argtypes = [vp, c.c_int, vp]
+        L.oracle_real_roots.restype = c.c_int
         L.oracle_five_point.argtypes = [vp, vp, vp]
         L.oracle_five_point.restype = c.c_int
         L.oracle_seven_point.argtypes = [vp, vp, vp]
@@ -118,6 +120,14 @@ def sample_table_f(pts1, pts2, n_iters):
 
 def update_num_iters(p, ep, m, max_iters):
     return lib().oracle_ransac_update_num_iters(p, ep, m, max_iters)
+
+
+def real_roots(coef):
+    coef = np.ascontiguousarray(coef, dtype=np.float64)
+    roots = np.zeros(10, dtype=np.float64)
+    n = lib().oracle_real_roots(_p(coef), len(coef) - 1, _p(roots))
+    assert n >= 0
+    return roots[:n].copy()
 
 
 def five_point(x1, x2):

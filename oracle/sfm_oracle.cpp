@@ -164,20 +164,38 @@ double horner(const double* c, int n, double x)
 }
 
 // Root of polynomial P (degree n, derivative dP of degree n-1) inside the
-// bracket (lo,hi) with P(lo) of sign flo and a sign change across it.
+// bracket (lo,hi) across which P changes sign; lo_neg says P(lo) < 0.
+// Newton steps, replaced by a bisection of the bracket whenever the Newton
+// step would leave the bracket or shrinks slower than by half.  Runs to a
+// fixed point (no tolerance), so the result depends on IEEE arithmetic only.
 double solve_bracket(const double* P, const double* dP, int n, double lo, double hi, bool lo_neg)
 {
+    double xl = lo_neg ? lo : hi;  // P(xl) < 0 < P(xh)
+    double xh = lo_neg ? hi : lo;
     double x = 0.5 * (lo + hi);
-    for (int it = 0; it < 200; it++) {
-        double f = horner(P, n, x);
+    double dxold = std::fabs(hi - lo);
+    double dx = dxold;
+    double f = horner(P, n, x);
+    double df = horner(dP, n - 1, x);
+    for (int it = 0; it < 300; it++) {
         if (f == 0.0) return x;
-        if ((f < 0.0) == lo_neg) lo = x; else hi = x;
-        double df = horner(dP, n - 1, x);
-        double xn = x - f / df;
-        if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-        if (xn == x) return x;
-        if (!(xn > lo && xn < hi)) return x;  // bracket has no interior double left
+        if (f < 0.0) xl = x; else xh = x;
+        const bool bisect = (((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) ||
+                            (std::fabs(2.0 * f) > std::fabs(dxold * df));
+        dxold = dx;
+        double xn;
+        if (bisect) {
+            dx = 0.5 * (xh - xl);
+            xn = xl + dx;
+            if (xn == xl || xn == xh) return x;
+        } else {
+            dx = f / df;
+            xn = x - dx;
+            if (xn == x) return x;
+        }
         x = xn;
+        f = horner(P, n, x);
+        df = horner(dP, n - 1, x);
     }
     return x;
 }
@@ -676,6 +694,12 @@ int oracle_sample_table_f(int count, const float* pts1, const float* pts2, int n
 int oracle_ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
 {
     return update_num_iters(p, ep, model_points, max_iters);
+}
+
+int oracle_real_roots(const double* coef, int degree, double* roots)
+{
+    if (degree < 1 || degree > 10) return -1;
+    return real_roots(coef, degree, roots);
 }
 
 int oracle_five_point(const double* x1, const double* x2, double* models)

@@ -73,6 +73,11 @@ int oracle_sample_table_f(int count, const float* pts1, const float* pts2,
 int oracle_ransac_update_num_iters(double p, double ep, int model_points,
                                    int max_iters);
 
+/* All real roots (ascending) of coef[0] + coef[1] z + ... + coef[degree] z^degree,
+ * degree 1..10: the root finder used by the two minimal solvers.  Returns the
+ * number of roots, -1 on a bad degree. */
+int oracle_real_roots(const double* coef, int degree, double* roots);
+
 /* Five-point solver on 5 normalised correspondences (x1: 5x2, x2: 5x2).
  * Writes up to 10 row-major 3x3 models with unit Frobenius norm, in
  * ascending order of the real root z.  Returns the model count. */

@@ -1,0 +1,95 @@
+"""ctypes binding of libsfm_gpu.so (the C ABI declared in include/sfm_gpu.h).
+
+There is no CPU fallback: if the library is missing or no GPU is present the
+calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsfm_gpu.so")
+
+DMATCH_DTYPE = np.dtype(
+    [("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")]
+)
+
+OK = 0
+ERR_ARG, ERR_HIP, ERR_NOT_U8, ERR_TOO_MANY, ERR_UNSUPPORTED, ERR_NOMEM, ERR_CAPACITY = (
+    -1, -2, -3, -4, -5, -6, -7)
+DESC_F32, DESC_U8 = 0, 1
+MODEL_ESSENTIAL, MODEL_FUNDAMENTAL = 0, 1
+RANSAC_ADAPTIVE, RANSAC_FIXED = 0, 1
+
+
+class MatchParams(ctypes.Structure):
+    _fields_ = [
+        ("ratio", ctypes.c_double),
+        ("model", ctypes.c_int32),
+        ("mode", ctypes.c_int32),
+        ("K", ctypes.c_double * 9),
+        ("prob", ctypes.c_double),
+        ("threshold_px", ctypes.c_double),
+        ("max_iters", ctypes.c_int32),
+        ("n_hyp", ctypes.c_int32),
+    ]
+
+
+class SfmGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sfm_gpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Loads libsfm_gpu.so; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "%s not found: build it with `python -m sfm_amd.build` (hipcc, gfx950)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp = c.c_void_p
+    L.sfm_gpu_version.restype = c.c_char_p
+    L.sfm_gpu_create.argtypes = [c.c_int, vp, c.POINTER(vp)]
+    L.sfm_gpu_destroy.argtypes = [vp]
+    L.sfm_gpu_destroy.restype = None
+    L.sfm_gpu_last_error_string.argtypes = [vp]
+    L.sfm_gpu_last_error_string.restype = c.c_char_p
+    L.sfm_gpu_synchronize.argtypes = [vp]
+    L.sfm_gpu_knn_match.argtypes = [vp, vp, c.c_int, c.c_size_t, vp, c.c_int, c.c_size_t,
+                                    c.c_int, c.c_int, c.c_int, vp, vp]
+    L.sfm_gpu_ratio_test.argtypes = [vp, vp, c.c_int, c.c_int, c.c_double, vp, vp]
+    L.sfm_gpu_ransac.argtypes = [vp, vp, vp, c.c_int, vp, c.c_int, c.c_double, c.c_double,
+                                 c.c_int, c.c_int, vp, c.c_int, vp, vp, vp, vp, vp]
+    L.sfm_gpu_image_create.argtypes = [vp, vp, c.c_int, c.c_size_t, c.c_int, c.c_int, vp, c.c_int,
+                                       c.POINTER(vp)]
+    L.sfm_gpu_image_destroy.argtypes = [vp, vp]
+    L.sfm_gpu_image_destroy.restype = None
+    L.sfm_gpu_image_rows.argtypes = [vp]
+    L.sfm_gpu_knn_match_images.argtypes = [vp, vp, vp, c.c_int, vp, vp, c.c_int]
+    L.sfm_gpu_match_pairs.argtypes = [vp, vp, vp, c.c_int, c.POINTER(MatchParams), vp, vp, vp,
+                                      c.c_int]
+    L.sfm_gpu_profile_enable.argtypes = [vp, c.c_int]
+    L.sfm_gpu_profile_reset.argtypes = [vp]
+    L.sfm_gpu_profile_query.argtypes = [vp, c.c_char_p, c.POINTER(c.c_double),
+                                        c.POINTER(c.c_int64)]
+    L.sfm_gpu_debug_set_knn_variant.argtypes = [vp, c.c_int]
+    L.sfm_gpu_debug_mfma_probe.argtypes = [vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def ptr(a):
+    """Host pointer of a numpy array, device pointer of an int, or NULL."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return ctypes.c_void_p(a)
+    return a.ctypes.data_as(ctypes.c_void_p)

@@ -1,0 +1,146 @@
+// Context object behind the C ABI: stream, grow-only device workspaces,
+// per-kernel event timers.
+#pragma once
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+
+#include "sfm_internal.h"
+
+namespace sfm {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    // Grow-only.  Contents are not preserved across a growth.
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+// Device image whose storage is one DevBuf (used for the temporaries of the
+// host-pointer entry points and for sfm_gpu_image).
+struct ImageStore {
+    DevBuf buf;
+    DevBuf kpbuf;
+    ImageDev d;
+    hipError_t shape(int n, bool with_kp)
+    {
+        int rows = ((n > 0 ? n : 1) + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
+        size_t bytes = (size_t)rows * (DIM + 12);
+        hipError_t e = buf.reserve(bytes);
+        if (e != hipSuccess) return e;
+        d.n = n;
+        d.rows_alloc = rows;
+        d.desc = buf.as<int8_t>();
+        d.cin = (int32_t*)(d.desc + (size_t)rows * DIM);
+        d.low = d.cin + rows;
+        d.qn = d.low + rows;
+        d.kp = nullptr;
+        if (with_kp) {
+            e = kpbuf.reserve((size_t)(n > 0 ? n : 1) * sizeof(float2));
+            if (e != hipSuccess) return e;
+            d.kp = kpbuf.as<float2>();
+        }
+        return hipSuccess;
+    }
+    void release()
+    {
+        buf.release();
+        kpbuf.release();
+    }
+};
+
+}  // namespace sfm
+
+struct sfm_gpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int knn_variant = -1;  // -1: planner decides
+
+    sfm::DevBuf raw_q, raw_t;
+    sfm::ImageStore tmp_q, tmp_t;
+    sfm::DevBuf partial, out, counts, redo, jobs, flags;
+    // ransac workspaces
+    sfm::DevBuf rs_pts, rs_table, rs_models, rs_counts, rs_mask, rs_misc;
+    // match_pairs workspaces
+    sfm::DevBuf mp_good, mp_pts, mp_ngood;
+
+    bool profiling = false;
+    std::map<std::string, sfm::KernelTimer> timers;
+
+    int fail(int code, const char* fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+namespace sfm {
+
+// RAII bracket around one kernel launch for the per-kernel timers.
+struct ProfScope {
+    sfm_gpu_ctx* c;
+    KernelTimer* t = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(sfm_gpu_ctx* ctx, const char* name) : c(ctx)
+    {
+        if (!c->profiling) return;
+        t = &c->timers[name];
+        t->name = name;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { t = nullptr; return; }
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~ProfScope()
+    {
+        if (!t) return;
+        (void)hipEventRecord(b, c->stream);
+        t->pending.emplace_back(a, b);
+    }
+};
+
+#define SFM_HIP(ctx, call)                                                                 \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return (ctx)->fail(e_ == hipErrorOutOfMemory ? SFM_GPU_ERR_NOMEM : SFM_GPU_ERR_HIP, \
+                               "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
+                               __FILE__, __LINE__);                                        \
+    } while (0)
+
+// implemented in ransac_kernels.hip / ransac_host.cpp
+int ransac_run(sfm_gpu_ctx* ctx, const double* pts1_dev_px, const double* pts2_dev_px, int n,
+               const int32_t* n_dev, const double* K, int model, double prob, double threshold_px,
+               int max_iters, int mode, const int32_t* sample_table_host, int n_hyp,
+               uint8_t* mask_host, double* model_out, int32_t* n_inliers, int32_t* iters_used,
+               int32_t* ok);
+
+}  // namespace sfm

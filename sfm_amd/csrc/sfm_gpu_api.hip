@@ -1,0 +1,345 @@
+// C ABI of libsfm_gpu: context, image preparation, k-NN matching entry points.
+#include <cstring>
+
+#include "sfm_ctx.h"
+
+using namespace sfm;
+
+namespace {
+
+// sfm_gpu_image handed to callers is the first member of its holder.
+struct ImageHolder {
+    sfm_gpu_image img;
+    ImageStore st;
+};
+
+int check_knn_args(sfm_gpu_ctx* ctx, int n_query, int n_train, int dim, int dtype, int k)
+{
+    if (n_query < 0 || n_train < 0) return ctx->fail(SFM_GPU_ERR_ARG, "negative row count");
+    if (dim != DIM) return ctx->fail(SFM_GPU_ERR_ARG, "dim must be 128, got %d", dim);
+    if (dtype != SFM_GPU_DESC_F32 && dtype != SFM_GPU_DESC_U8)
+        return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "unknown descriptor dtype %d", dtype);
+    if (k < 1 || k > 2) return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "k must be 1 or 2, got %d", k);
+    if (n_train >= (1 << 18))
+        return ctx->fail(SFM_GPU_ERR_TOO_MANY, "n_train %d >= 2^18 (cv::BFMatcher limit)", n_train);
+    return SFM_GPU_OK;
+}
+
+// Uploads (or reads in place) n rows and runs the preparation kernel into st.
+int prepare_image(sfm_gpu_ctx* ctx, ImageStore& st, DevBuf& raw, const void* desc, int n,
+                  size_t step, int dtype, bool on_device, bool with_kp)
+{
+    SFM_HIP(ctx, st.shape(n, with_kp));
+    const size_t rowbytes = dtype == SFM_GPU_DESC_F32 ? DIM * 4 : DIM;
+    if (n > 0 && step < rowbytes) return ctx->fail(SFM_GPU_ERR_ARG, "row step %zu < row bytes", step);
+    const void* src = desc;
+    size_t src_step = step;
+    if (!on_device && n > 0) {
+        SFM_HIP(ctx, raw.reserve((size_t)n * rowbytes));
+        SFM_HIP(ctx, hipMemcpy2DAsync(raw.p, rowbytes, desc, step, rowbytes, n, hipMemcpyHostToDevice,
+                                      ctx->stream));
+        src = raw.p;
+        src_step = rowbytes;
+    }
+    SFM_HIP(ctx, ctx->flags.reserve(64));
+    {
+        ProfScope ps(ctx, "prep_rows");
+        SFM_HIP(ctx, launch_prep_rows(ctx->stream, src, src_step, dtype, n, st.d, ctx->flags.as<int32_t>()));
+    }
+    return SFM_GPU_OK;
+}
+
+int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
+                  sfm_gpu_dmatch* matches, int32_t* counts, bool out_on_device)
+{
+    const int nq = q.n, nt = t.n;
+    if (nq == 0) return SFM_GPU_OK;
+    const KnnPlan plan = plan_knn(nq, nt, 1, ctx->knn_variant);
+    SFM_HIP(ctx, ctx->partial.reserve((size_t)plan.n_splits * q.rows_alloc * sizeof(uint4)));
+    SFM_HIP(ctx, ctx->redo.reserve(((size_t)nq + 1) * 4));
+    SFM_HIP(ctx, ctx->jobs.reserve(sizeof(KnnJob)));
+    sfm_gpu_dmatch* out_dev = matches;
+    int32_t* cnt_dev = counts;
+    if (!out_on_device) {
+        SFM_HIP(ctx, ctx->out.reserve((size_t)nq * k * sizeof(sfm_gpu_dmatch)));
+        SFM_HIP(ctx, ctx->counts.reserve((size_t)nq * 4));
+        out_dev = ctx->out.as<sfm_gpu_dmatch>();
+        cnt_dev = ctx->counts.as<int32_t>();
+    }
+    KnnJob job;
+    job.q_desc = q.desc;
+    job.t_desc = t.desc;
+    job.t_cin = t.cin;
+    job.t_low = t.low;
+    job.q_qn = q.qn;
+    job.partial = ctx->partial.as<uint4>();
+    job.out = out_dev;
+    job.counts = cnt_dev;
+    job.redo = ctx->redo.as<int32_t>();
+    job.n_query = nq;
+    job.n_train = nt;
+    job.q_rows_alloc = q.rows_alloc;
+    job.t_chunks = nt > 0 ? (nt + CHUNK - 1) / CHUNK : 0;
+    SFM_HIP(ctx, hipMemcpyAsync(ctx->jobs.p, &job, sizeof(job), hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP(ctx, hipMemsetAsync(ctx->redo.p, 0, 4, ctx->stream));
+    {
+        ProfScope ps(ctx, "knn2_mfma");
+        SFM_HIP(ctx, launch_knn2(ctx->stream, ctx->jobs.as<KnnJob>(), 1, q.rows_alloc, plan));
+    }
+    {
+        ProfScope ps(ctx, "knn_finalize");
+        SFM_HIP(ctx, launch_knn_finalize(ctx->stream, ctx->jobs.as<KnnJob>(), 1, nq, plan.n_splits, k));
+    }
+    {
+        ProfScope ps(ctx, "knn_redo");
+        SFM_HIP(ctx, launch_knn_redo(ctx->stream, ctx->jobs.as<KnnJob>(), 1, k));
+    }
+    if (!out_on_device) {
+        SFM_HIP(ctx, hipMemcpyAsync(matches, out_dev, (size_t)nq * k * sizeof(sfm_gpu_dmatch),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP(ctx, hipMemcpyAsync(counts, cnt_dev, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SFM_GPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sfm_gpu_version(void) { return "sfm_gpu 0.1 gfx950"; }
+
+int sfm_gpu_create(int device_id, void* hip_stream, sfm_gpu_ctx** out)
+{
+    if (!out) return SFM_GPU_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev)
+        return SFM_GPU_ERR_HIP;
+    if (hipSetDevice(device_id) != hipSuccess) return SFM_GPU_ERR_HIP;
+    sfm_gpu_ctx* c = new (std::nothrow) sfm_gpu_ctx();
+    if (!c) return SFM_GPU_ERR_NOMEM;
+    c->device = device_id;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return SFM_GPU_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    if (c->flags.reserve(64) != hipSuccess || hipMemsetAsync(c->flags.p, 0, 64, c->stream) != hipSuccess) {
+        delete c;
+        return SFM_GPU_ERR_HIP;
+    }
+    *out = c;
+    return SFM_GPU_OK;
+}
+
+void sfm_gpu_destroy(sfm_gpu_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->timers)
+        for (auto& pr : kv.second.pending) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    DevBuf* bufs[] = {&c->raw_q, &c->raw_t, &c->partial, &c->out, &c->counts, &c->redo, &c->jobs,
+                      &c->flags, &c->rs_pts, &c->rs_table, &c->rs_models, &c->rs_counts, &c->rs_mask,
+                      &c->rs_misc, &c->mp_good, &c->mp_pts, &c->mp_ngood};
+    for (DevBuf* b : bufs) b->release();
+    c->tmp_q.release();
+    c->tmp_t.release();
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* sfm_gpu_last_error_string(const sfm_gpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int sfm_gpu_synchronize(sfm_gpu_ctx* c)
+{
+    if (!c) return SFM_GPU_ERR_ARG;
+    SFM_HIP(c, hipStreamSynchronize(c->stream));
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_knn_match(sfm_gpu_ctx* ctx, const void* query, int n_query, size_t query_step,
+                      const void* train, int n_train, size_t train_step, int dim, int dtype, int k,
+                      sfm_gpu_dmatch* matches, int32_t* counts)
+{
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    int rc = check_knn_args(ctx, n_query, n_train, dim, dtype, k);
+    if (rc) return rc;
+    if (n_query == 0) return SFM_GPU_OK;
+    if (!query || !matches || !counts || (n_train > 0 && !train))
+        return ctx->fail(SFM_GPU_ERR_ARG, "null pointer argument");
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, hipMemsetAsync(ctx->flags.p, 0, 4, ctx->stream));
+    rc = prepare_image(ctx, ctx->tmp_q, ctx->raw_q, query, n_query, query_step, dtype, false, false);
+    if (rc) return rc;
+    rc = prepare_image(ctx, ctx->tmp_t, ctx->raw_t, train, n_train, train_step, dtype, false, false);
+    if (rc) return rc;
+    int32_t flag = 0;
+    SFM_HIP(ctx, hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    rc = knn_on_images(ctx, ctx->tmp_q.d, ctx->tmp_t.d, k, matches, counts, false);
+    if (rc) return rc;
+    if (flag)
+        return ctx->fail(SFM_GPU_ERR_NOT_U8, "descriptor values must be integers in 0..255");
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_ratio_test(const sfm_gpu_dmatch* matches, const int32_t* counts, int n_query, int k,
+                       double ratio, int32_t* keep_rows, int32_t* n_keep)
+{
+    if (!matches || !counts || !keep_rows || !n_keep || n_query < 0 || k < 2) return SFM_GPU_ERR_ARG;
+    int n = 0;
+    for (int r = 0; r < n_query; r++) {
+        if (counts[r] < 2) continue;
+        const sfm_gpu_dmatch* m = matches + (size_t)r * k;
+        if ((double)m[0].distance < ratio * (double)m[1].distance) keep_rows[n++] = r;
+    }
+    *n_keep = n;
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_image_create(sfm_gpu_ctx* ctx, const void* desc, int n, size_t step, int dim, int dtype,
+                         const float* keypoints_xy, int desc_on_device, sfm_gpu_image** out)
+{
+    if (!ctx || !out) return SFM_GPU_ERR_ARG;
+    *out = nullptr;
+    int rc = check_knn_args(ctx, n, 0, dim, dtype, 2);
+    if (rc) return rc;
+    if (n >= (1 << 18)) return ctx->fail(SFM_GPU_ERR_TOO_MANY, "image rows %d >= 2^18", n);
+    if (n > 0 && !desc) return ctx->fail(SFM_GPU_ERR_ARG, "null descriptor pointer");
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    ImageHolder* h = new (std::nothrow) ImageHolder();
+    if (!h) return ctx->fail(SFM_GPU_ERR_NOMEM, "host allocation failed");
+    SFM_HIP(ctx, hipMemsetAsync(ctx->flags.p, 0, 4, ctx->stream));
+    rc = prepare_image(ctx, h->st, ctx->raw_q, desc, n, step, dtype, desc_on_device != 0,
+                       keypoints_xy != nullptr);
+    if (rc == SFM_GPU_OK && keypoints_xy && n > 0) {
+        hipError_t e = hipMemcpyAsync(h->st.d.kp, keypoints_xy, (size_t)n * sizeof(float2),
+                                      desc_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                      ctx->stream);
+        if (e != hipSuccess) rc = ctx->fail(SFM_GPU_ERR_HIP, "keypoint copy failed: %s", hipGetErrorString(e));
+    }
+    int32_t flag = 0;
+    if (rc == SFM_GPU_OK) {
+        hipError_t e = hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = ctx->fail(SFM_GPU_ERR_HIP, "sync failed: %s", hipGetErrorString(e));
+        else if (flag) rc = ctx->fail(SFM_GPU_ERR_NOT_U8, "descriptor values must be integers in 0..255");
+    }
+    if (rc != SFM_GPU_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        h->st.release();
+        delete h;
+        return rc;
+    }
+    h->img.d = h->st.d;
+    *out = &h->img;
+    return SFM_GPU_OK;
+}
+
+void sfm_gpu_image_destroy(sfm_gpu_ctx* ctx, sfm_gpu_image* img)
+{
+    if (!img) return;
+    ImageHolder* h = (ImageHolder*)img;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    h->st.release();
+    delete h;
+}
+
+int sfm_gpu_image_rows(const sfm_gpu_image* img) { return img ? img->d.n : -1; }
+
+int sfm_gpu_knn_match_images(sfm_gpu_ctx* ctx, const sfm_gpu_image* query, const sfm_gpu_image* train,
+                             int k, sfm_gpu_dmatch* matches, int32_t* counts, int out_on_device)
+{
+    if (!ctx || !query || !train) return SFM_GPU_ERR_ARG;
+    int rc = check_knn_args(ctx, query->d.n, train->d.n, DIM, SFM_GPU_DESC_U8, k);
+    if (rc) return rc;
+    if (query->d.n > 0 && (!matches || !counts)) return ctx->fail(SFM_GPU_ERR_ARG, "null output pointer");
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    return knn_on_images(ctx, query->d, train->d, k, matches, counts, out_on_device != 0);
+}
+
+// ---- measurement ------------------------------------------------------
+
+int sfm_gpu_profile_enable(sfm_gpu_ctx* c, int on)
+{
+    if (!c) return SFM_GPU_ERR_ARG;
+    c->profiling = on != 0;
+    return SFM_GPU_OK;
+}
+
+static int drain_timers(sfm_gpu_ctx* c)
+{
+    SFM_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& kv : c->timers) {
+        for (auto& pr : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                kv.second.total_ms += ms;
+                kv.second.launches++;
+            }
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_profile_reset(sfm_gpu_ctx* c)
+{
+    if (!c) return SFM_GPU_ERR_ARG;
+    int rc = drain_timers(c);
+    if (rc) return rc;
+    c->timers.clear();
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_profile_query(sfm_gpu_ctx* c, const char* kernel, double* total_ms, int64_t* launches)
+{
+    if (!c || !kernel) return SFM_GPU_ERR_ARG;
+    int rc = drain_timers(c);
+    if (rc) return rc;
+    auto it = c->timers.find(kernel);
+    if (total_ms) *total_ms = it == c->timers.end() ? 0.0 : it->second.total_ms;
+    if (launches) *launches = it == c->timers.end() ? 0 : it->second.launches;
+    return SFM_GPU_OK;
+}
+
+// ---- test hooks (declared in sfm_gpu_debug.h) ---------------------------
+
+int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* c, int variant)
+{
+    if (!c) return SFM_GPU_ERR_ARG;
+    c->knn_variant = variant;
+    return SFM_GPU_OK;
+}
+
+// c[32*32] = a[32][32] * b^T where b is given as [32 columns][32 k]; host pointers.
+int sfm_gpu_debug_mfma_probe(sfm_gpu_ctx* ctx, const int8_t* a, const int8_t* b, int32_t* c)
+{
+    if (!ctx || !a || !b || !c) return SFM_GPU_ERR_ARG;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, ctx->rs_misc.reserve(1024 + 1024 + 4096));
+    int8_t* da = ctx->rs_misc.as<int8_t>();
+    int8_t* db = da + 1024;
+    int32_t* dc = (int32_t*)(da + 2048);
+    SFM_HIP(ctx, hipMemcpyAsync(da, a, 1024, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP(ctx, hipMemcpyAsync(db, b, 1024, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP(ctx, launch_mfma_layout_probe(ctx->stream, da, db, dc));
+    SFM_HIP(ctx, hipMemcpyAsync(c, dc, 4096, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFM_GPU_OK;
+}
+
+}  // extern "C"

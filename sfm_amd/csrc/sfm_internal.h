@@ -1,0 +1,97 @@
+// Internal declarations shared by the HIP translation units of libsfm_gpu.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "sfm_gpu.h"
+
+namespace sfm {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int DIM = 128;
+// Train rows are swept in chunks of 256: inside a chunk the running top-2 keeps
+// an 8-bit row index packed under the 24-bit distance key.
+constexpr int CHUNK = 256;
+// Descriptor stores are allocated in multiples of this many rows so that every
+// workgroup shape may read whole query blocks and whole train chunks.
+constexpr int ROW_ALIGN = 1024;
+// x = dot + cin is what the MFMA chain leaves in the accumulator.
+// cin = floor(Tn/2) + KEY_OFFSET keeps x in [64, 5226560] for every pair of
+// 0..255-valued rows, so (x << 9) fits 32 bits.
+constexpr int KEY_OFFSET = 2080896;
+constexpr int PAD_CIN = 0x7FFFFF;  // padding rows rank behind every real row
+constexpr uint32_t KEY_NONE = 0xFFFFFFu;
+
+// One image's descriptors as the distance kernel wants them.
+//   desc[r][d]  = value - 128 as int8 (byte = value ^ 0x80)
+//   qn[r]       = sum_d (value-128)^2                (query-side norm)
+//   cin[r]      = floor(Tn/2) + KEY_OFFSET, Tn = sum_d (value-127)^2 - 128
+//   low[r]      = (Tn & 1) << 8 | (r & 255)
+// so that for query q and train t:
+//   d2(q,t) = qn[q] + 2*(dot(~q, t) + cin[t]) + (low[t] >> 8) - 2*KEY_OFFSET
+struct ImageDev {
+    int n = 0;
+    int rows_alloc = 0;
+    int8_t* desc = nullptr;
+    int32_t* cin = nullptr;
+    int32_t* low = nullptr;
+    int32_t* qn = nullptr;
+    float2* kp = nullptr;
+};
+
+struct KnnJob {
+    const int8_t* q_desc;
+    const int8_t* t_desc;
+    const int32_t* t_cin;
+    const int32_t* t_low;
+    const int32_t* q_qn;
+    uint4* partial;       // [n_splits][q_rows_alloc] {key1, idx1, key2, idx2}
+    sfm_gpu_dmatch* out;  // [n_query][k]
+    int32_t* counts;      // [n_query]
+    int32_t* redo;        // [0] = count, [1..] = query rows needing the float-ranked pass
+    int n_query;
+    int n_train;
+    int q_rows_alloc;
+    int t_chunks;
+};
+
+struct KernelTimer {
+    std::string name;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace sfm
+
+struct sfm_gpu_image {
+    sfm::ImageDev d;
+};
+
+// launchers implemented in knn_kernels.hip
+namespace sfm {
+
+hipError_t launch_prep_rows(hipStream_t s, const void* src, size_t step, int dtype, int n,
+                            const ImageDev& img, int32_t* err_flag);
+// Picks the workgroup shape and split count for a batch of equally sized jobs.
+struct KnnPlan {
+    int n_splits;
+    int chunks_per_split;
+    int q_per_block;
+    int variant;
+};
+KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant);
+hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_rows_alloc_max,
+                       const KnnPlan& plan);
+hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_query_max,
+                               int n_splits, int k);
+hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int k);
+hipError_t launch_mfma_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c);
+
+}  // namespace sfm

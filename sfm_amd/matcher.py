@@ -1,0 +1,261 @@
+"""Host-side mirror of the reference's interface for the matching path.
+
+The reference calls, per image pair (/root/reference/main.cpp:181-231):
+
+    matcher->knnMatch(descriptorsL, descriptorsR, matches, 2);       // :184
+    if (m[0].distance < 0.7 * m[1].distance) ...                      // :192
+    findEssentialMat(ptsL, ptsR, K, FM_RANSAC, 0.99, 1.0, inliers);   // :224
+
+The classes below keep those names and argument meanings and forward to the
+C ABI of libsfm_gpu.so.  numpy arrays stand in for cv::Mat; a structured array
+with the cv::DMatch fields stands in for vector<vector<DMatch>>.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import (DMATCH_DTYPE, DESC_F32, DESC_U8, MODEL_ESSENTIAL, MODEL_FUNDAMENTAL,
+                   RANSAC_ADAPTIVE, RANSAC_FIXED, MatchParams, SfmGpuError, ptr)
+
+FM_RANSAC = 8  # cv::FM_RANSAC == cv::RANSAC
+
+
+class Context:
+    """One GPU + one HIP stream (sfm_gpu_create)."""
+
+    def __init__(self, device_id=0, stream=None):
+        self._L = _lib.lib()
+        h = ctypes.c_void_p()
+        rc = self._L.sfm_gpu_create(device_id, ctypes.c_void_p(stream) if stream else None,
+                                    ctypes.byref(h))
+        if rc != 0:
+            raise SfmGpuError(rc, "sfm_gpu_create failed (no GPU, or bad device id %d)" % device_id)
+        self.handle = h
+        self.device_id = device_id
+
+    def check(self, rc):
+        if rc != 0:
+            raise SfmGpuError(rc, self._L.sfm_gpu_last_error_string(self.handle).decode())
+
+    def synchronize(self):
+        self.check(self._L.sfm_gpu_synchronize(self.handle))
+
+    def close(self):
+        if self.handle:
+            self._L.sfm_gpu_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # measurement support
+    def profile_enable(self, on=True):
+        self.check(self._L.sfm_gpu_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        self.check(self._L.sfm_gpu_profile_reset(self.handle))
+
+    def profile_query(self, kernel):
+        ms = ctypes.c_double(0)
+        n = ctypes.c_int64(0)
+        self.check(self._L.sfm_gpu_profile_query(self.handle, kernel.encode(), ctypes.byref(ms),
+                                                 ctypes.byref(n)))
+        return ms.value, n.value
+
+
+def _desc_args(a):
+    a = np.asarray(a)
+    if a.ndim != 2:
+        raise ValueError("descriptors must be 2-D")
+    if a.dtype == np.float32:
+        dtype = DESC_F32
+    elif a.dtype == np.uint8:
+        dtype = DESC_U8
+    else:
+        raise TypeError("descriptors must be float32 (CV_32F) or uint8 (CV_8U)")
+    if a.shape[0] > 0 and a.strides[1] != a.itemsize:
+        a = np.ascontiguousarray(a)
+    step = a.strides[0] if a.shape[0] > 0 else a.shape[1] * a.itemsize
+    return a, dtype, step
+
+
+class BFMatcher:
+    """cv::BFMatcher(NORM_L2) stand-in; only knnMatch, the method main.cpp:184 calls."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def knnMatch(self, queryDescriptors, trainDescriptors, k=2):
+        """Returns (matches, counts): matches[nq, k] with cv::DMatch fields,
+        counts[nq] = number of valid entries per row (= min(k, n_train))."""
+        q, qd, qstep = _desc_args(queryDescriptors)
+        t, td, tstep = _desc_args(trainDescriptors)
+        if qd != td:
+            raise TypeError("query and train descriptor types differ")
+        nq, nt = q.shape[0], t.shape[0]
+        dim = q.shape[1]
+        if nt > 0 and t.shape[1] != dim:
+            raise ValueError("query and train descriptor lengths differ")
+        matches = np.zeros((nq, k), dtype=DMATCH_DTYPE)
+        counts = np.zeros(nq, dtype=np.int32)
+        L = self.ctx._L
+        self.ctx.check(L.sfm_gpu_knn_match(self.ctx.handle, ptr(q), nq, qstep, ptr(t), nt, tstep,
+                                           dim, qd, k, ptr(matches), ptr(counts)))
+        return matches, counts
+
+
+def ratio_test(matches, counts, ratio=0.7):
+    """main.cpp:189-197: rows whose best distance < ratio * second-best (double)."""
+    L = _lib.lib()
+    matches = np.ascontiguousarray(matches)
+    nq, k = matches.shape
+    keep = np.zeros(max(nq, 1), dtype=np.int32)
+    n = ctypes.c_int32(0)
+    rc = L.sfm_gpu_ratio_test(ptr(matches), ptr(np.ascontiguousarray(counts, dtype=np.int32)), nq,
+                              k, float(ratio), ptr(keep), ctypes.byref(n))
+    if rc != 0:
+        raise SfmGpuError(rc, "sfm_gpu_ratio_test: bad arguments")
+    return keep[:n.value].copy()
+
+
+def _ransac(ctx, pts1, pts2, K, model, prob, threshold, max_iters, mode, sample_table, n_hyp,
+            mask):
+    pts1 = np.ascontiguousarray(pts1, dtype=np.float64).reshape(-1, 2)
+    pts2 = np.ascontiguousarray(pts2, dtype=np.float64).reshape(-1, 2)
+    n = pts1.shape[0]
+    if pts2.shape[0] != n:
+        raise ValueError("point arrays differ in length")
+    if mask is None:
+        mask = np.zeros(n, dtype=np.uint8)
+    Kc = None if K is None else np.ascontiguousarray(K, dtype=np.float64)
+    st = None
+    if sample_table is not None:
+        st = np.ascontiguousarray(sample_table, dtype=np.int32)
+        n_hyp = st.shape[0]
+    out = np.zeros((3, 3), dtype=np.float64)
+    n_inl = ctypes.c_int32(0)
+    iters = ctypes.c_int32(0)
+    ok = ctypes.c_int32(0)
+    ctx.check(ctx._L.sfm_gpu_ransac(ctx.handle, ptr(pts1), ptr(pts2), n, ptr(Kc), model, prob,
+                                    threshold, max_iters, mode, ptr(st), n_hyp, ptr(mask), ptr(out),
+                                    ctypes.byref(n_inl), ctypes.byref(iters), ctypes.byref(ok)))
+    return dict(ok=ok.value, model=out, mask=mask, n_inliers=n_inl.value, iters=iters.value)
+
+
+def findEssentialMat(ctx, points1, points2, cameraMatrix, method=FM_RANSAC, prob=0.999,
+                     threshold=1.0, maxIters=1000, mask=None, mode=RANSAC_ADAPTIVE,
+                     sample_table=None, n_hyp=0):
+    """cv::findEssentialMat(points1, points2, cameraMatrix, method, prob,
+    threshold[, maxIters], mask) as called at main.cpp:224.  Returns (E, mask);
+    E is None when no model was found (OpenCV returns an empty Mat), and the
+    mask passed in is then left untouched."""
+    if method != FM_RANSAC:
+        raise NotImplementedError("only FM_RANSAC is on the accelerated path")
+    r = _ransac(ctx, points1, points2, cameraMatrix, MODEL_ESSENTIAL, prob, threshold, maxIters,
+                mode, sample_table, n_hyp, mask)
+    r["E"] = r["model"] if r["ok"] else None
+    return r["E"], r["mask"], r
+
+
+def findFundamentalMat(ctx, points1, points2, method=FM_RANSAC, ransacReprojThreshold=3.0,
+                       confidence=0.99, maxIters=1000, mask=None, mode=RANSAC_ADAPTIVE,
+                       sample_table=None, n_hyp=0):
+    """cv::findFundamentalMat(points1, points2, FM_RANSAC, threshold, confidence)."""
+    if method != FM_RANSAC:
+        raise NotImplementedError("only FM_RANSAC is on the accelerated path")
+    r = _ransac(ctx, points1, points2, None, MODEL_FUNDAMENTAL, confidence, ransacReprojThreshold,
+                maxIters, mode, sample_table, n_hyp, mask)
+    r["F"] = r["model"] if r["ok"] else None
+    return r["F"], r["mask"], r
+
+
+class Image:
+    """One image's descriptors (+ keypoints) resident on the GPU
+    (descriptors[i] / keypoints[i] of main.cpp:175-178)."""
+
+    def __init__(self, ctx, descriptors, keypoints_xy=None, device_ptrs=None):
+        """descriptors: numpy [n,128] float32/uint8; keypoints_xy: numpy [n,2]
+        float32.  device_ptrs=(desc_ptr, n, step, dtype, kp_ptr) uses memory
+        already on the GPU instead."""
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        L = ctx._L
+        if device_ptrs is not None:
+            dptr, n, step, dtype, kptr = device_ptrs
+            rc = L.sfm_gpu_image_create(ctx.handle, ctypes.c_void_p(dptr), n, step, 128, dtype,
+                                        ctypes.c_void_p(kptr) if kptr else None, 1, ctypes.byref(h))
+        else:
+            d, dtype, step = _desc_args(descriptors)
+            kp = None
+            if keypoints_xy is not None:
+                kp = np.ascontiguousarray(keypoints_xy, dtype=np.float32).reshape(-1, 2)
+                if kp.shape[0] != d.shape[0]:
+                    raise ValueError("keypoints and descriptors differ in length")
+            rc = L.sfm_gpu_image_create(ctx.handle, ptr(d), d.shape[0], step, d.shape[1], dtype,
+                                        ptr(kp), 0, ctypes.byref(h))
+        ctx.check(rc)
+        self.handle = h
+        self.n = L.sfm_gpu_image_rows(h)
+
+    def close(self):
+        if self.handle and self.ctx.handle:
+            self.ctx._L.sfm_gpu_image_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def knn_match_images(ctx, query_img, train_img, k=2, out_device=None):
+    """knnMatch between prepared images.  out_device=(matches_ptr, counts_ptr)
+    leaves the results on the GPU and only enqueues the work."""
+    L = ctx._L
+    if out_device is not None:
+        ctx.check(L.sfm_gpu_knn_match_images(ctx.handle, query_img.handle, train_img.handle, k,
+                                             ctypes.c_void_p(out_device[0]),
+                                             ctypes.c_void_p(out_device[1]), 1))
+        return None
+    matches = np.zeros((query_img.n, k), dtype=DMATCH_DTYPE)
+    counts = np.zeros(query_img.n, dtype=np.int32)
+    ctx.check(L.sfm_gpu_knn_match_images(ctx.handle, query_img.handle, train_img.handle, k,
+                                         ptr(matches), ptr(counts), 0))
+    return matches, counts
+
+
+def match_pairs(ctx, images, pairs, K, ratio=0.7, model=MODEL_ESSENTIAL, mode=RANSAC_ADAPTIVE,
+                prob=0.99, threshold=1.0, max_iters=1000, n_hyp=0, want_matches=False):
+    """The loop body of match() (main.cpp:175-231, 267) over a list of pairs.
+    Returns (n_good, n_inliers[, inlier_matches list])."""
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    n_pairs = pairs.shape[0]
+    arr = (ctypes.c_void_p * len(images))(*[im.handle for im in images])
+    p = MatchParams()
+    p.ratio = ratio
+    p.model = model
+    p.mode = mode
+    Kc = np.ascontiguousarray(K if K is not None else np.eye(3), dtype=np.float64).reshape(9)
+    for i in range(9):
+        p.K[i] = Kc[i]
+    p.prob = prob
+    p.threshold_px = threshold
+    p.max_iters = max_iters
+    p.n_hyp = n_hyp
+    n_good = np.zeros(n_pairs, dtype=np.int32)
+    n_inl = np.zeros(n_pairs, dtype=np.int32)
+    cap = 0
+    out = None
+    if want_matches:
+        cap = max([images[i].n for i in pairs[:, 0]] + [1])
+        out = np.zeros((n_pairs, cap), dtype=DMATCH_DTYPE)
+    ctx.check(ctx._L.sfm_gpu_match_pairs(ctx.handle, arr, ptr(pairs), n_pairs, ctypes.byref(p),
+                                         ptr(n_good), ptr(n_inl), ptr(out), cap))
+    if want_matches:
+        return n_good, n_inl, [out[i, :n_inl[i]].copy() for i in range(n_pairs)]
+    return n_good, n_inl

@@ -1,0 +1,201 @@
+"""Known-answer tests that pin the CPU oracle without OpenCV.
+
+The reference holds no tests or golden vectors for this path (parity
+unpinned); these are the answers that can be derived independently: exact
+integer distances, OpenCV's documented tie order, the cv::RNG recurrence, the
+RANSAC iteration-count formula and the algebraic properties of an essential
+matrix.
+"""
+import numpy as np
+
+from sfm_amd import synth
+
+
+def test_knn_hand_rows(oracle):
+    t = np.zeros((3, 128), np.float32)
+    q = np.zeros((1, 128), np.float32)
+    t[1, 5] = 1      # d2 = 1
+    t[2, 7] = 2      # d2 = 4
+    m, c = oracle.knn_match(q, t, 2)
+    assert c[0] == 2
+    assert m["trainIdx"][0].tolist() == [0, 1]
+    assert m["distance"][0].tolist() == [0.0, 1.0]
+    m, c = oracle.knn_match(q, t[1:], 2)
+    assert m["trainIdx"][0].tolist() == [0, 1] and m["distance"][0].tolist() == [1.0, 2.0]
+
+
+def test_knn_duplicates_keep_lowest_index(oracle):
+    rng = np.random.default_rng(0)
+    t = rng.integers(0, 256, (40, 128)).astype(np.float32)
+    t[31] = t[3]
+    t[17] = t[3]
+    q = t[3:4].copy()
+    m, c = oracle.knn_match(q, t, 2)
+    assert m["trainIdx"][0].tolist() == [3, 17]
+    assert m["distance"][0].tolist() == [0.0, 0.0]
+
+
+def test_knn_short_rows_and_empty(oracle):
+    q = np.zeros((2, 128), np.float32)
+    t = np.full((1, 128), 255, np.float32)
+    m, c = oracle.knn_match(q, t, 2)
+    assert c.tolist() == [1, 1]
+    assert m["trainIdx"][:, 0].tolist() == [0, 0] and m["trainIdx"][:, 1].tolist() == [-1, -1]
+    # all-0 vs all-255: d2 = 128*255^2 = 8323200
+    assert m["distance"][0, 0] == np.float32(np.sqrt(np.float64(8323200.0)))
+    m, c = oracle.knn_match(q, np.zeros((0, 128), np.float32), 2)
+    assert c.tolist() == [0, 0]
+
+
+def test_knn_float_collision_prefers_lower_index(oracle):
+    # two different d2 >= 2^22 with the same float32 sqrt: the ranking is on the
+    # float, so the lower train index wins although its d2 is larger
+    base = None
+    for d2 in range(1 << 22, (1 << 22) + 4000):
+        if np.float32(np.sqrt(np.float64(d2))) == np.float32(np.sqrt(np.float64(d2 + 1))):
+            base = d2
+            break
+    assert base is not None
+    q = np.zeros((1, 128), np.float32)
+
+    def row_with_d2(target):
+        r = np.zeros(128, np.float32)
+        rem = target
+        for i in range(128):
+            v = min(255, int(np.floor(np.sqrt(rem))))
+            r[i] = v
+            rem -= v * v
+        assert rem == 0, rem
+        return r
+    t = np.stack([row_with_d2(base + 1), row_with_d2(base), np.full(128, 255, np.float32)])
+    m, c = oracle.knn_match(q, t, 2)
+    assert m["trainIdx"][0].tolist() == [0, 1]
+    assert m["distance"][0, 0] == m["distance"][0, 1]
+
+
+def test_ratio_test_in_double(oracle):
+    m = np.zeros((3, 2), dtype=oracle.DMATCH_DTYPE)
+    c = np.array([2, 2, 1], np.int32)
+    # 0.7f * 10 vs 0.7 * 10: pick d0 so that float and double products disagree
+    d1 = np.float32(10.0)
+    d0 = np.float32(0.7) * d1      # = 7.0000005 > 0.7*10 = 7.000000000000001 in double
+    m["distance"][0] = (d0, d1)
+    m["distance"][1] = (np.float32(6.9999995), d1)
+    m["distance"][2] = (1.0, 0.0)
+    keep = oracle.ratio_test(m, c, 0.7)
+    assert keep.tolist() == [1]
+
+
+def test_cv_rng_stream(oracle):
+    assert oracle.rng_next(8).tolist() == [0x07c09cf5, 0xbac3439c, 0x99ae7b8c, 0x37275f45,
+                                           0x40637cc7, 0xaf98a118, 0x059ae535, 0x8902c9a0]
+    assert oracle.rng_uniform(0, 1000, 8).tolist() == [605, 4, 940, 173, 831, 512, 301, 280]
+    assert oracle.rng_uniform(0, 8443, 8).tolist() == [7633, 1287, 271, 8145, 5310, 7965, 7610, 3872]
+
+
+def test_sample_table_distinct_and_stream(oracle):
+    tab = oracle.sample_table(8443, 5, 4)
+    assert tab[0].tolist() == [7633, 1287, 271, 8145, 5310]
+    assert tab[1].tolist()[:3] == [7965, 7610, 3872]
+    small = oracle.sample_table(6, 5, 200)
+    assert all(len(set(r.tolist())) == 5 for r in small)
+    assert small.min() >= 0 and small.max() < 6
+
+
+def test_update_num_iters(oracle):
+    assert oracle.update_num_iters(0.99, 1 - 0.91, 5, 1000) == 5
+    assert oracle.update_num_iters(0.99, 0.5, 5, 1000) == 145
+    assert oracle.update_num_iters(0.99, 1.0, 5, 1000) == 1000
+    assert oracle.update_num_iters(0.99, 0.0, 5, 1000) == 0
+
+
+def test_threshold_scaling(oracle):
+    _, thr = oracle.normalize_points(np.zeros((1, 2)), synth.REF_K, 1.0)
+    assert abs(thr - 3.4628976e-4) < 1e-10
+    assert np.float32(thr * thr) == np.float32(1.199166e-07)
+
+
+def _true_E_pair(seed, n=60):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, (n, 3))
+    X[:, 2] += 5
+    R = synth._rot(rng.normal(size=3), 0.07)
+    t = rng.normal(size=3)
+    t /= np.linalg.norm(t)
+    x1 = X[:, :2] / X[:, 2:]
+    X2 = X @ R.T + t
+    x2 = X2[:, :2] / X2[:, 2:]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = tx @ R
+    return x1, x2, E / np.linalg.norm(E)
+
+
+def test_five_point_recovers_true_E(oracle):
+    for seed in range(10):
+        x1, x2, E = _true_E_pair(seed)
+        ms = oracle.five_point(x1[:5], x2[:5])
+        assert 1 <= len(ms) <= 10
+        best = min(min(np.abs(M - E).max(), np.abs(M + E).max()) for M in ms)
+        assert best < 1e-8, (seed, best)
+        for M in ms:
+            assert abs(np.linalg.norm(M) - 1) < 1e-12
+            assert abs(np.linalg.det(M)) < 1e-9
+            assert np.abs(2 * M @ M.T @ M - np.trace(M @ M.T) * M).max() < 1e-8
+            res = [abs(np.r_[x2[i], 1] @ M @ np.r_[x1[i], 1]) for i in range(5)]
+            assert max(res) < 1e-10
+
+
+def test_sampson_zero_on_noise_free_inliers(oracle):
+    x1, x2, E = _true_E_pair(3)
+    err = oracle.sampson_errors(E, x1, x2)
+    assert err.max() < 1e-25
+    # scale invariance and a hand value
+    E2 = np.zeros((3, 3))
+    E2[0, 1] = -1.0
+    E2[1, 0] = 1.0   # x2^T E x1 = x2.y*x1.x - x2.x*x1.y
+    e = oracle.sampson_errors(E2, np.array([[1.0, 0.0]]), np.array([[0.0, 2.0]]))
+    # s = 2 ; Ex1 = (0,1,0) ; E^T x2 = (2,0,0) ; err = 4 / (0+1+4+0)
+    assert e[0] == np.float32(0.8)
+
+
+def test_seven_point_contains_true_F(oracle):
+    x1, x2, E = _true_E_pair(5)
+    K = synth.REF_K
+    p1 = (np.c_[x1, np.ones(len(x1))] @ K.T)[:, :2].astype(np.float32)
+    p2 = (np.c_[x2, np.ones(len(x2))] @ K.T)[:, :2].astype(np.float32)
+    Fs = oracle.seven_point(p1[:7], p2[:7])
+    assert 1 <= len(Fs) <= 3
+    errs = [oracle.symepi_errors(F, p1, p2).max() for F in Fs]
+    assert min(errs) < 1e-2   # float32 pixel rounding only
+    for F in Fs:
+        assert abs(np.linalg.det(F / np.linalg.norm(F))) < 1e-9
+
+
+def test_ransac_adaptive_matches_geometry(oracle):
+    p1, p2, is_in, E = synth.two_view(1500, 11, inlier_frac=0.85, noise_px=0.3)
+    r = oracle.ransac(p1, p2, synth.REF_K, prob=0.99, threshold=1.0, want_counts=True)
+    assert r["ok"] == 1
+    assert r["iters"] < 100
+    assert r["n_inliers"] == int(r["mask"].sum())
+    assert (r["mask"].astype(bool) & ~is_in).sum() <= 5
+    assert r["n_inliers"] > 0.9 * is_in.sum()
+    M = r["model"]
+    assert min(np.abs(M - E).max(), np.abs(M + E).max()) < 0.05
+
+
+def test_ransac_degenerate_counts(oracle):
+    p1, p2, _, _ = synth.two_view(5, 1, inlier_frac=1.0, noise_px=0.0)
+    sentinel = np.full(4, 7, np.uint8)
+    r = oracle.ransac(p1[:4], p2[:4], synth.REF_K, mask_init=sentinel)
+    assert r["ok"] == 0 and r["mask"].tolist() == [7, 7, 7, 7]   # n < 5: mask untouched
+    r = oracle.ransac(p1, p2, synth.REF_K)
+    assert r["ok"] == 1 and r["mask"].tolist() == [1] * 5        # n == 5: direct solve
+
+
+def test_ransac_fixed_count_is_replayable(oracle):
+    # the adaptive loop is a prefix replay of the fixed-count scores
+    p1, p2, _, _ = synth.two_view(800, 21, inlier_frac=0.8)
+    ra = oracle.ransac(p1, p2, synth.REF_K, want_counts=True)
+    rf = oracle.ransac(p1, p2, synth.REF_K, fixed_count=ra["iters"], want_counts=True)
+    assert (ra["counts"][:ra["iters"]] == rf["counts"][:ra["iters"]]).all()
+    assert (ra["mask"] == rf["mask"]).all()
