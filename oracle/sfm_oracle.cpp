@@ -225,29 +225,30 @@ int real_roots(const double* cin, int n, double* roots)
     prev[0] = -D[1][0] / D[1][1];
     if (n == 1) { roots[0] = prev[0]; return 1; }
     for (int k = 2; k <= n; k++) {
+        // interval t = [e_t, e_{t+1}] with e_0 = -B, e_1..e_m the critical
+        // points (clamped to [-B, B]), e_{m+1} = B; every interval is handled
+        // independently of the others
         mcur = 0;
-        double lo = -B;
-        double flo = horner(D[k], k, lo);
         for (int t = 0; t <= mprev; t++) {
+            double lo = (t == 0) ? -B : prev[t - 1];
             double hi = (t < mprev) ? prev[t] : B;
+            if (lo < -B) lo = -B;
+            if (lo > B) lo = B;
+            if (hi < -B) hi = -B;
             if (hi > B) hi = B;
             if (!(hi > lo)) continue;
+            double flo = horner(D[k], k, lo);
             double fhi = horner(D[k], k, hi);
             if (flo == 0.0) {
                 if (mcur < 10) cur[mcur++] = lo;
             } else if (fhi != 0.0 && ((flo < 0.0) != (fhi < 0.0))) {
                 if (mcur < 10) cur[mcur++] = solve_bracket(D[k], D[k - 1], k, lo, hi, flo < 0.0);
+            } else if (fhi == 0.0 && t == mprev) {
+                if (mcur < 10) cur[mcur++] = hi;
             }
-            lo = hi;
-            flo = fhi;
         }
-        if (flo == 0.0 && mcur < 10) cur[mcur++] = lo;
         for (int i = 0; i < mcur; i++) prev[i] = cur[i];
         mprev = mcur;
-        if (mprev == 0) {
-            // derivative chain lost its critical points: the polynomial is
-            // monotone from here on, keep going with a single interval
-        }
     }
     for (int i = 0; i < mprev; i++) roots[i] = prev[i];
     return mprev;
