@@ -20,6 +20,13 @@ int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* ctx, int variant);
  * distance kernel loads its operands. */
 int sfm_gpu_debug_mfma_probe(sfm_gpu_ctx* ctx, const int8_t* a, const int8_t* b, int32_t* c);
 
+/* Per-hypothesis data of the last sfm_gpu_ransac call on this context: the
+ * sample table [n_hyp][m], the number of candidate models per hypothesis, the
+ * inlier counts [n_hyp][10] (-1 = no such model) and the models
+ * [n_hyp][10][9].  Host pointers; any may be NULL. */
+int sfm_gpu_debug_ransac_dump(sfm_gpu_ctx* ctx, int n_hyp, int32_t* table, int32_t* nmodels,
+                              int32_t* counts, double* models);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,98 @@
+// Glue between the k-NN output and RANSAC for one image pair, on the device:
+// the ratio test with point gathering (/root/reference/main.cpp:187-198) and
+// the final inlier selection (/root/reference/main.cpp:225-231).
+#include "ransac_dev.h"
+
+namespace sfm {
+
+namespace {
+
+// Order-preserving compaction of the rows with flag set, 1024 rows per step.
+// Returns this thread's output slot (or -1) and advances *base.
+__device__ __forceinline__ int compact_slot(bool flag, int* wsum, int* base)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(flag);
+    const int lane_prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(mask);
+    __syncthreads();
+    int wave_prefix = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        const int c = wsum[w];
+        if (w < wave) wave_prefix += c;
+        total += c;
+    }
+    const int b = *base;
+    __syncthreads();
+    if (tid == 0) *base = b + total;
+    __syncthreads();
+    return flag ? b + wave_prefix + lane_prefix : -1;
+}
+
+__global__ void __launch_bounds__(1024) ratio_compact_kernel(const PairDev* __restrict__ pairs, double ratio)
+{
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const PairDev pd = pairs[blockIdx.x];
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int start = 0; start < pd.n_query; start += 1024) {
+        const int q = start + threadIdx.x;
+        bool flag = false;
+        sfm_gpu_dmatch m0;
+        if (q < pd.n_query && pd.counts[q] >= 2) {
+            m0 = pd.knn[2 * q];
+            const sfm_gpu_dmatch m1 = pd.knn[2 * q + 1];
+            flag = (double)m0.distance < ratio * (double)m1.distance;
+        }
+        const int slot = compact_slot(flag, wsum, &base);
+        if (slot >= 0) {
+            pd.good[slot] = m0;
+            if (pd.kp_q && pd.kp_t) {
+                const float2 a = pd.kp_q[m0.queryIdx];
+                const float2 b = pd.kp_t[m0.trainIdx];
+                pd.px1[2 * slot] = (double)a.x;
+                pd.px1[2 * slot + 1] = (double)a.y;
+                pd.px2[2 * slot] = (double)b.x;
+                pd.px2[2 * slot + 1] = (double)b.y;
+            }
+        }
+    }
+    if (threadIdx.x == 0) *pd.n_good = base;
+}
+
+__global__ void __launch_bounds__(1024) inlier_compact_kernel(const PairDev* __restrict__ pairs)
+{
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const PairDev pd = pairs[blockIdx.x];
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    const int n = *pd.n_good;
+    const bool ok = pd.result[R_OK] != 0;
+    if (ok) {
+        for (int start = 0; start < n; start += 1024) {
+            const int i = start + threadIdx.x;
+            const bool flag = i < n && pd.mask[i] != 0;
+            const int slot = compact_slot(flag, wsum, &base);
+            if (slot >= 0 && pd.inliers && slot < pd.capacity) pd.inliers[slot] = pd.good[i];
+        }
+    }
+    if (threadIdx.x == 0) *pd.n_inliers = base;
+}
+
+}  // namespace
+
+hipError_t launch_ratio_compact(hipStream_t s, const PairDev* pairs, int n_pairs, double ratio)
+{
+    hipLaunchKernelGGL(ratio_compact_kernel, dim3(n_pairs), dim3(1024), 0, s, pairs, ratio);
+    return hipGetLastError();
+}
+
+hipError_t launch_inlier_compact(hipStream_t s, const PairDev* pairs, int n_pairs)
+{
+    hipLaunchKernelGGL(inlier_compact_kernel, dim3(n_pairs), dim3(1024), 0, s, pairs);
+    return hipGetLastError();
+}
+
+}  // namespace sfm

@@ -1,0 +1,508 @@
+// Host side of the RANSAC path and of the pair-list driver.
+//
+// sfm_gpu_ransac     <- findEssentialMat(...)            /root/reference/main.cpp:224
+// sfm_gpu_match_pairs<- the loop body of match()          /root/reference/main.cpp:175-231, 267
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ransac_dev.h"
+#include "sfm_ctx.h"
+
+using namespace sfm;
+
+namespace {
+
+int cv_round(double v) { return (int)std::nearbyint(v); }
+
+// cv::RANSACUpdateNumIters (OpenCV 4.5.5 calib3d ptsetreg.cpp).
+int update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = std::max(p, 0.);
+    p = std::min(p, 1.);
+    ep = std::max(ep, 0.);
+    ep = std::min(ep, 1.);
+    double num = std::max(1. - p, DBL_MIN);
+    double denom = 1. - std::pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = std::log(num);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : cv_round(num / denom);
+}
+
+struct RansacParams {
+    int model;
+    int mode;
+    double K[9];
+    double prob;
+    double threshold_px;
+    int max_iters;
+    int n_hyp;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Bytes of per-problem RANSAC workspace for `cap` points and `hyp_cap` hypotheses.
+size_t ransac_ws_bytes(int cap, int hyp_cap, int m)
+{
+    size_t b = 0;
+    b += align_up((size_t)cap * 16, 256) * 2;            // x1, x2
+    b += align_up((size_t)cap * 8, 256) * 2;             // f1, f2
+    b += align_up((size_t)hyp_cap * m * 4, 256);         // table
+    b += align_up((size_t)hyp_cap * 90 * 8, 256);        // models
+    b += align_up((size_t)hyp_cap * 4, 256);             // nmodels
+    b += align_up((size_t)hyp_cap * 10 * 4, 256);        // counts
+    b += 256;                                            // result
+    b += align_up((size_t)cap, 256);                     // mask
+    b += 256;                                            // model_out
+    return b;
+}
+
+void carve_ransac(RansacProb& pb, char* base, int cap, int hyp_cap, int m)
+{
+    char* p = base;
+    auto take = [&](size_t bytes) { char* r = p; p += align_up(bytes, 256); return r; };
+    pb.x1 = (double*)take((size_t)cap * 16);
+    pb.x2 = (double*)take((size_t)cap * 16);
+    pb.f1 = (float*)take((size_t)cap * 8);
+    pb.f2 = (float*)take((size_t)cap * 8);
+    pb.table = (int32_t*)take((size_t)hyp_cap * m * 4);
+    pb.models = (double*)take((size_t)hyp_cap * 90 * 8);
+    pb.nmodels = (int32_t*)take((size_t)hyp_cap * 4);
+    pb.counts = (int32_t*)take((size_t)hyp_cap * 10 * 4);
+    pb.result = (int32_t*)take(256);
+    pb.mask = (uint8_t*)take((size_t)cap);
+    pb.model_out = (double*)take(256);
+}
+
+int fill_params(sfm_gpu_ctx* ctx, RansacProb& pb, const RansacParams& rp)
+{
+    if (rp.model != SFM_GPU_MODEL_ESSENTIAL && rp.model != SFM_GPU_MODEL_FUNDAMENTAL)
+        return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "unknown RANSAC model %d", rp.model);
+    if (rp.mode != SFM_GPU_RANSAC_ADAPTIVE && rp.mode != SFM_GPU_RANSAC_FIXED)
+        return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "unknown RANSAC mode %d", rp.mode);
+    if (!(rp.prob > 0 && rp.prob < 1)) return ctx->fail(SFM_GPU_ERR_ARG, "prob must be in (0,1)");
+    if (rp.mode == SFM_GPU_RANSAC_FIXED && rp.n_hyp < 1)
+        return ctx->fail(SFM_GPU_ERR_ARG, "n_hyp must be >= 1 in fixed mode");
+    pb.model = rp.model;
+    pb.m = rp.model == SFM_GPU_MODEL_ESSENTIAL ? 5 : 7;
+    double thr = rp.threshold_px;
+    pb.fx = pb.fy = 1.0;
+    pb.cx = pb.cy = 0.0;
+    if (rp.model == SFM_GPU_MODEL_ESSENTIAL) {
+        pb.fx = rp.K[0];
+        pb.fy = rp.K[4];
+        pb.cx = rp.K[2];
+        pb.cy = rp.K[5];
+        thr /= (pb.fx + pb.fy) / 2;  // findEssentialMat: threshold /= (fx+fy)/2
+    }
+    pb.tf = (float)(thr * thr);
+    pb.tlo = (double)pb.tf * (1.0 - 1.0 / 1048576.0);
+    pb.thi = (double)pb.tf * (1.0 + 1.0 / 1048576.0);
+    return SFM_GPU_OK;
+}
+
+// Runs RANSAC for n_prob problems whose descriptors (with every device pointer
+// set) are in `probs`.  `results` receives n_prob * R_COUNT ints.  On return
+// the masks and models are on the device; the stream has been synchronised.
+int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int hyp_cap,
+                 const RansacParams& rp, const int32_t* custom_table_host, std::vector<int32_t>& results)
+{
+    const int n_prob = (int)probs.size();
+    const int m = probs[0].m;
+    hipStream_t s = ctx->stream;
+    SFM_HIP(ctx, ctx->rs_misc.reserve(sizeof(RansacProb) * (size_t)n_prob));
+    RansacProb* dprobs = ctx->rs_misc.as<RansacProb>();
+    SFM_HIP(ctx, hipMemcpyAsync(dprobs, probs.data(), sizeof(RansacProb) * n_prob, hipMemcpyHostToDevice, s));
+    {
+        ProfScope ps(ctx, "ransac_prep");
+        SFM_HIP(ctx, launch_ransac_prep(s, dprobs, n_prob, cap));
+    }
+    results.assign((size_t)n_prob * R_COUNT, 0);
+    auto fetch_results = [&]() -> int {
+        for (int p = 0; p < n_prob; ++p)
+            SFM_HIP(ctx, hipMemcpyAsync(&results[(size_t)p * R_COUNT], probs[p].result, R_COUNT * 4,
+                                        hipMemcpyDeviceToHost, s));
+        SFM_HIP(ctx, hipStreamSynchronize(s));
+        return SFM_GPU_OK;
+    };
+
+    if (rp.mode == SFM_GPU_RANSAC_FIXED) {
+        const int nh = rp.n_hyp;
+        if (custom_table_host) {
+            // caller-supplied table (single problem, n > m checked by the caller)
+            SFM_HIP(ctx, hipMemcpyAsync(probs[0].table, custom_table_host, (size_t)nh * m * 4,
+                                        hipMemcpyHostToDevice, s));
+            const int32_t valid = nh;
+            SFM_HIP(ctx, hipMemcpyAsync(probs[0].result + R_VALID, &valid, 4, hipMemcpyHostToDevice, s));
+        } else {
+            ProfScope ps(ctx, "ransac_table");
+            SFM_HIP(ctx, launch_ransac_table(s, dprobs, n_prob, 0, nh));
+        }
+        {
+            ProfScope ps(ctx, "ransac_solve");
+            SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, 0, nh));
+        }
+        {
+            ProfScope ps(ctx, "ransac_score");
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, 0, nh));
+        }
+        {
+            ProfScope ps(ctx, "ransac_select");
+            SFM_HIP(ctx, launch_ransac_select(s, dprobs, n_prob, nh));
+        }
+        {
+            ProfScope ps(ctx, "ransac_mask");
+            SFM_HIP(ctx, launch_ransac_mask(s, dprobs, n_prob, cap));
+        }
+        return fetch_results();
+    }
+
+    // Adaptive mode: hypotheses are scored in batches on the GPU and OpenCV's
+    // sequential loop (RANSACPointSetRegistrator::run) is replayed over the
+    // counts, which reproduces its order-dependent early termination exactly.
+    struct St {
+        int n = 0, niters = 0, iter = 0, best = 0, hyp = -1, q = -1;
+        bool done = false, direct = false, failed = false;
+    };
+    std::vector<St> st(n_prob);
+    const int max_it = std::max(rp.max_iters, 1);
+    int rc = fetch_results();
+    if (rc) return rc;
+    for (int p = 0; p < n_prob; ++p) {
+        st[p].n = results[(size_t)p * R_COUNT + R_N];
+        st[p].niters = max_it;
+        if (st[p].n < m) { st[p].done = true; st[p].failed = true; }
+    }
+    std::vector<int32_t> counts;
+    int done_rows = 0;
+    while (done_rows < max_it) {
+        int want = 0;
+        for (auto& t : st)
+            if (!t.done) want = std::max(want, t.niters - done_rows);
+        if (want <= 0) break;
+        int b = done_rows == 0 ? 32 : 128;
+        b = std::min(b, std::min(want, max_it - done_rows));
+        {
+            ProfScope ps(ctx, "ransac_table");
+            SFM_HIP(ctx, launch_ransac_table(s, dprobs, n_prob, done_rows, b));
+        }
+        {
+            ProfScope ps(ctx, "ransac_solve");
+            SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, done_rows, b));
+        }
+        {
+            ProfScope ps(ctx, "ransac_score");
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, done_rows, b));
+        }
+        counts.resize((size_t)n_prob * b * 10);
+        for (int p = 0; p < n_prob; ++p) {
+            if (st[p].done) continue;
+            SFM_HIP(ctx, hipMemcpyAsync(&counts[(size_t)p * b * 10], probs[p].counts + (size_t)done_rows * 10,
+                                        (size_t)b * 40, hipMemcpyDeviceToHost, s));
+        }
+        rc = fetch_results();
+        if (rc) return rc;
+        for (int p = 0; p < n_prob; ++p) {
+            St& t = st[p];
+            if (t.done) continue;
+            const int valid = results[(size_t)p * R_COUNT + R_VALID];
+            t.direct = results[(size_t)p * R_COUNT + R_DIRECT] != 0;
+            if (t.direct) {
+                // n == m: one direct solve, every point an inlier
+                const int c0 = counts[(size_t)p * b * 10];
+                t.done = true;
+                t.failed = c0 < 0;
+                t.hyp = 0;
+                t.q = 0;
+                t.best = t.n;
+                t.iter = 0;
+                continue;
+            }
+            const int32_t* c = &counts[(size_t)p * b * 10];
+            for (; t.iter < t.niters && t.iter < done_rows + b; ++t.iter) {
+                if (t.iter >= valid) {  // getSubset failed
+                    if (t.iter == 0) t.failed = true;
+                    t.done = true;
+                    break;
+                }
+                const int32_t* row = c + (size_t)(t.iter - done_rows) * 10;
+                for (int q = 0; q < 10; ++q) {
+                    const int good = row[q];
+                    if (good < 0) continue;
+                    if (good > std::max(t.best, m - 1)) {
+                        t.best = good;
+                        t.hyp = t.iter;
+                        t.q = q;
+                        t.niters = update_num_iters(rp.prob, (double)(t.n - good) / t.n, m, t.niters);
+                    }
+                }
+            }
+            if (t.iter >= t.niters) t.done = true;
+        }
+        done_rows += b;
+    }
+    for (int p = 0; p < n_prob; ++p) {
+        St& t = st[p];
+        int32_t* r = &results[(size_t)p * R_COUNT];
+        const bool ok = !t.failed && t.best > 0 && t.hyp >= 0;
+        r[R_OK] = ok ? 1 : 0;
+        r[R_HYP] = ok ? t.hyp : -1;
+        r[R_Q] = ok ? t.q : -1;
+        r[R_NINL] = ok ? t.best : 0;
+        r[R_ITERS] = t.iter;
+        SFM_HIP(ctx, hipMemcpyAsync(probs[p].result, r, 5 * 4, hipMemcpyHostToDevice, s));
+    }
+    {
+        ProfScope ps(ctx, "ransac_mask");
+        SFM_HIP(ctx, launch_ransac_mask(s, dprobs, n_prob, cap));
+    }
+    SFM_HIP(ctx, hipStreamSynchronize(s));
+    return SFM_GPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int n, const double* K,
+                   int model, double prob, double threshold_px, int max_iters, int mode,
+                   const int32_t* sample_table, int n_hyp, uint8_t* mask, double* model_out,
+                   int32_t* n_inliers, int32_t* iters_used, int32_t* ok)
+{
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    if (n < 0 || !ok || (n > 0 && (!pts1 || !pts2 || !mask)) || !model_out)
+        return ctx->fail(SFM_GPU_ERR_ARG, "null pointer or negative count");
+    if (model == SFM_GPU_MODEL_ESSENTIAL && !K) return ctx->fail(SFM_GPU_ERR_ARG, "K is required");
+    if (sample_table && mode != SFM_GPU_RANSAC_FIXED)
+        return ctx->fail(SFM_GPU_ERR_ARG, "a sample table needs SFM_GPU_RANSAC_FIXED");
+    *ok = 0;
+    if (n_inliers) *n_inliers = 0;
+    if (iters_used) *iters_used = 0;
+    RansacParams rp;
+    rp.model = model;
+    rp.mode = mode;
+    if (K) memcpy(rp.K, K, sizeof(rp.K));
+    else memset(rp.K, 0, sizeof(rp.K));
+    rp.prob = prob;
+    rp.threshold_px = threshold_px;
+    rp.max_iters = max_iters;
+    rp.n_hyp = n_hyp;
+    std::vector<RansacProb> probs(1);
+    int rc = fill_params(ctx, probs[0], rp);
+    if (rc) return rc;
+    const int m = probs[0].m;
+    if (n < m) return SFM_GPU_OK;  // OpenCV: returns false, mask untouched
+    if (sample_table && n > m)
+        for (long long i = 0; i < (long long)n_hyp * m; ++i)
+            if (sample_table[i] < 0 || sample_table[i] >= n)
+                return ctx->fail(SFM_GPU_ERR_ARG, "sample table entry %lld out of range", i);
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    const int hyp_cap = mode == SFM_GPU_RANSAC_FIXED ? n_hyp : std::max(max_iters, 1);
+    const size_t px_bytes = align_up((size_t)n * 16, 256);
+    SFM_HIP(ctx, ctx->rs_pts.reserve(px_bytes * 2 + 256));
+    SFM_HIP(ctx, ctx->rs_models.reserve(ransac_ws_bytes(n, hyp_cap, m)));
+    char* pbase = ctx->rs_pts.as<char>();
+    double* dpx1 = (double*)pbase;
+    double* dpx2 = (double*)(pbase + px_bytes);
+    int32_t* dn = (int32_t*)(pbase + 2 * px_bytes);
+    SFM_HIP(ctx, hipMemcpyAsync(dpx1, pts1, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP(ctx, hipMemcpyAsync(dpx2, pts2, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP(ctx, hipMemcpyAsync(dn, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+    probs[0].px1 = dpx1;
+    probs[0].px2 = dpx2;
+    probs[0].n_ptr = dn;
+    carve_ransac(probs[0], ctx->rs_models.as<char>(), n, hyp_cap, m);
+    ctx->dbg_table = probs[0].table;
+    ctx->dbg_counts = probs[0].counts;
+    ctx->dbg_nmodels = probs[0].nmodels;
+    ctx->dbg_models = probs[0].models;
+    ctx->dbg_hyp_cap = hyp_cap;
+    ctx->dbg_m = m;
+    std::vector<int32_t> results;
+    rc = ransac_batch(ctx, probs, n, hyp_cap, rp, (sample_table && n > m) ? sample_table : nullptr, results);
+    if (rc) return rc;
+    *ok = results[R_OK];
+    if (iters_used) *iters_used = results[R_ITERS];
+    if (results[R_OK]) {
+        if (n_inliers) *n_inliers = results[R_NINL];
+        SFM_HIP(ctx, hipMemcpyAsync(mask, probs[0].mask, n, hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP(ctx, hipMemcpyAsync(model_out, probs[0].model_out, 72, hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SFM_GPU_OK;
+}
+
+// Test hook: per-hypothesis data of the last sfm_gpu_ransac call on this
+// context.  Any output pointer may be null.  n_hyp rows are copied.
+int sfm_gpu_debug_ransac_dump(sfm_gpu_ctx* ctx, int n_hyp, int32_t* table, int32_t* nmodels,
+                              int32_t* counts, double* models)
+{
+    if (!ctx || n_hyp < 0 || n_hyp > ctx->dbg_hyp_cap || !ctx->dbg_table)
+        return ctx ? ctx->fail(SFM_GPU_ERR_ARG, "no RANSAC run to dump, or n_hyp too large") : SFM_GPU_ERR_ARG;
+    hipStream_t s = ctx->stream;
+    if (table) SFM_HIP(ctx, hipMemcpyAsync(table, ctx->dbg_table, (size_t)n_hyp * ctx->dbg_m * 4, hipMemcpyDeviceToHost, s));
+    if (nmodels) SFM_HIP(ctx, hipMemcpyAsync(nmodels, ctx->dbg_nmodels, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, s));
+    if (counts) SFM_HIP(ctx, hipMemcpyAsync(counts, ctx->dbg_counts, (size_t)n_hyp * 40, hipMemcpyDeviceToHost, s));
+    if (models) SFM_HIP(ctx, hipMemcpyAsync(models, ctx->dbg_models, (size_t)n_hyp * 720, hipMemcpyDeviceToHost, s));
+    SFM_HIP(ctx, hipStreamSynchronize(s));
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const int32_t* pairs,
+                        int n_pairs, const sfm_gpu_match_params* params, int32_t* n_good,
+                        int32_t* n_inliers, sfm_gpu_dmatch* inlier_matches, int match_capacity)
+{
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    if (n_pairs < 0 || !params || (n_pairs > 0 && (!images || !pairs || !n_good || !n_inliers)))
+        return ctx->fail(SFM_GPU_ERR_ARG, "null pointer or negative pair count");
+    if (n_pairs == 0) return SFM_GPU_OK;
+    RansacParams rp;
+    rp.model = params->model;
+    rp.mode = params->mode;
+    memcpy(rp.K, params->K, sizeof(rp.K));
+    rp.prob = params->prob;
+    rp.threshold_px = params->threshold_px;
+    rp.max_iters = params->max_iters;
+    rp.n_hyp = params->n_hyp;
+    RansacProb proto;
+    int rc = fill_params(ctx, proto, rp);
+    if (rc) return rc;
+    const int m = proto.m;
+    const int hyp_cap = rp.mode == SFM_GPU_RANSAC_FIXED ? rp.n_hyp : std::max(rp.max_iters, 1);
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+
+    int nq_max = 1, nt_max = 1, qalloc_max = ROW_ALIGN;
+    for (int p = 0; p < n_pairs; ++p) {
+        const sfm_gpu_image* iq = images[pairs[2 * p]];
+        const sfm_gpu_image* it = images[pairs[2 * p + 1]];
+        if (!iq || !it) return ctx->fail(SFM_GPU_ERR_ARG, "null image in pair %d", p);
+        if (!iq->d.kp || !it->d.kp)
+            return ctx->fail(SFM_GPU_ERR_ARG, "pair %d: images need keypoints for RANSAC", p);
+        nq_max = std::max(nq_max, iq->d.n);
+        nt_max = std::max(nt_max, it->d.n);
+        qalloc_max = std::max(qalloc_max, iq->d.rows_alloc);
+    }
+    if (inlier_matches && match_capacity < nq_max)
+        return ctx->fail(SFM_GPU_ERR_CAPACITY, "match_capacity %d < largest query image %d",
+                         match_capacity, nq_max);
+
+    // pairs are processed in groups that share one launch per stage
+    const size_t per_pair_ransac = ransac_ws_bytes(nq_max, hyp_cap, m);
+    int group = (int)std::min<size_t>((size_t)n_pairs,
+                                      std::max<size_t>(1, ((size_t)3 << 30) / (per_pair_ransac + 1)));
+    group = std::min(group, 256);
+    const KnnPlan plan_probe = plan_knn(nq_max, nt_max, group, ctx->knn_variant);
+    const size_t partial_b = align_up((size_t)plan_probe.n_splits * qalloc_max * sizeof(uint4), 256);
+    const size_t out_b = align_up((size_t)nq_max * 2 * sizeof(sfm_gpu_dmatch), 256);
+    const size_t cnt_b = align_up((size_t)nq_max * 4, 256);
+    const size_t redo_b = align_up(((size_t)nq_max + 1) * 4, 256);
+    const size_t good_b = align_up((size_t)nq_max * sizeof(sfm_gpu_dmatch), 256);
+    const size_t px_b = align_up((size_t)nq_max * 16, 256);
+    const size_t inl_b = inlier_matches ? align_up((size_t)match_capacity * sizeof(sfm_gpu_dmatch), 256) : 0;
+    SFM_HIP(ctx, ctx->partial.reserve(partial_b * group));
+    SFM_HIP(ctx, ctx->out.reserve(out_b * group));
+    SFM_HIP(ctx, ctx->counts.reserve(cnt_b * group));
+    SFM_HIP(ctx, ctx->redo.reserve(redo_b * group));
+    SFM_HIP(ctx, ctx->mp_good.reserve((good_b + inl_b) * group));
+    SFM_HIP(ctx, ctx->mp_pts.reserve(px_b * 2 * group));
+    SFM_HIP(ctx, ctx->mp_ngood.reserve(256 * (size_t)group));
+    SFM_HIP(ctx, ctx->rs_models.reserve(per_pair_ransac * group));
+    SFM_HIP(ctx, ctx->jobs.reserve((sizeof(KnnJob) + sizeof(PairDev)) * (size_t)group));
+
+    std::vector<KnnJob> jobs;
+    std::vector<PairDev> pds;
+    std::vector<RansacProb> probs;
+    std::vector<int32_t> results;
+    std::vector<int32_t> ng(group * 2);
+    for (int g0 = 0; g0 < n_pairs; g0 += group) {
+        const int g = std::min(group, n_pairs - g0);
+        jobs.assign(g, KnnJob());
+        pds.assign(g, PairDev());
+        probs.assign(g, proto);
+        const KnnPlan plan = plan_knn(nq_max, nt_max, g, ctx->knn_variant);
+        for (int i = 0; i < g; ++i) {
+            const ImageDev& q = images[pairs[2 * (g0 + i)]]->d;
+            const ImageDev& t = images[pairs[2 * (g0 + i) + 1]]->d;
+            KnnJob& j = jobs[i];
+            j.q_desc = q.desc;
+            j.t_desc = t.desc;
+            j.t_cin = t.cin;
+            j.t_low = t.low;
+            j.q_qn = q.qn;
+            j.partial = (uint4*)(ctx->partial.as<char>() + partial_b * i);
+            j.out = (sfm_gpu_dmatch*)(ctx->out.as<char>() + out_b * i);
+            j.counts = (int32_t*)(ctx->counts.as<char>() + cnt_b * i);
+            j.redo = (int32_t*)(ctx->redo.as<char>() + redo_b * i);
+            j.n_query = q.n;
+            j.n_train = t.n;
+            j.q_rows_alloc = q.rows_alloc;
+            j.t_chunks = t.n > 0 ? (t.n + CHUNK - 1) / CHUNK : 0;
+            SFM_HIP(ctx, hipMemsetAsync(j.redo, 0, 4, s));
+            PairDev& pd = pds[i];
+            pd.knn = j.out;
+            pd.counts = j.counts;
+            pd.kp_q = q.kp;
+            pd.kp_t = t.kp;
+            pd.good = (sfm_gpu_dmatch*)(ctx->mp_good.as<char>() + (good_b + inl_b) * i);
+            pd.inliers = inlier_matches ? (sfm_gpu_dmatch*)((char*)pd.good + good_b) : nullptr;
+            pd.px1 = (double*)(ctx->mp_pts.as<char>() + px_b * 2 * i);
+            pd.px2 = (double*)(ctx->mp_pts.as<char>() + px_b * 2 * i + px_b);
+            pd.n_good = (int32_t*)(ctx->mp_ngood.as<char>() + 256 * (size_t)i);
+            pd.n_inliers = pd.n_good + 1;
+            pd.n_query = q.n;
+            pd.capacity = match_capacity;
+            RansacProb& pb = probs[i];
+            pb.px1 = pd.px1;
+            pb.px2 = pd.px2;
+            pb.n_ptr = pd.n_good;
+            carve_ransac(pb, ctx->rs_models.as<char>() + per_pair_ransac * i, nq_max, hyp_cap, m);
+            pd.mask = pb.mask;
+            pd.result = pb.result;
+        }
+        KnnJob* djobs = ctx->jobs.as<KnnJob>();
+        PairDev* dpds = (PairDev*)(ctx->jobs.as<char>() + sizeof(KnnJob) * (size_t)group);
+        SFM_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), sizeof(KnnJob) * g, hipMemcpyHostToDevice, s));
+        SFM_HIP(ctx, hipMemcpyAsync(dpds, pds.data(), sizeof(PairDev) * g, hipMemcpyHostToDevice, s));
+        {
+            ProfScope ps(ctx, "knn2_mfma");
+            SFM_HIP(ctx, launch_knn2(s, djobs, g, qalloc_max, plan));
+        }
+        {
+            ProfScope ps(ctx, "knn_finalize");
+            SFM_HIP(ctx, launch_knn_finalize(s, djobs, g, nq_max, plan.n_splits, 2));
+        }
+        {
+            ProfScope ps(ctx, "knn_redo");
+            SFM_HIP(ctx, launch_knn_redo(s, djobs, g, 2));
+        }
+        {
+            ProfScope ps(ctx, "ratio_compact");
+            SFM_HIP(ctx, launch_ratio_compact(s, dpds, g, params->ratio));
+        }
+        rc = ransac_batch(ctx, probs, nq_max, hyp_cap, rp, nullptr, results);
+        if (rc) return rc;
+        {
+            ProfScope ps(ctx, "inlier_compact");
+            SFM_HIP(ctx, launch_inlier_compact(s, dpds, g));
+        }
+        for (int i = 0; i < g; ++i)
+            SFM_HIP(ctx, hipMemcpyAsync(&ng[2 * i], pds[i].n_good, 8, hipMemcpyDeviceToHost, s));
+        SFM_HIP(ctx, hipStreamSynchronize(s));
+        for (int i = 0; i < g; ++i) {
+            n_good[g0 + i] = ng[2 * i];
+            n_inliers[g0 + i] = ng[2 * i + 1];
+            if (inlier_matches && ng[2 * i + 1] > 0)
+                SFM_HIP(ctx, hipMemcpyAsync(inlier_matches + (size_t)(g0 + i) * match_capacity,
+                                            pds[i].inliers, (size_t)ng[2 * i + 1] * sizeof(sfm_gpu_dmatch),
+                                            hipMemcpyDeviceToHost, s));
+        }
+        SFM_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return SFM_GPU_OK;
+}
+
+}  // extern "C"

@@ -1,8 +1,901 @@
-// placeholder, replaced below
+// Batched RANSAC for gfx950: sample-table generation, one wavefront per
+// hypothesis minimal solvers (five-point essential, seven-point fundamental),
+// scoring of every candidate model against every correspondence, winner
+// selection and inlier mask.
+//
+// Replaces the arithmetic behind
+//     findEssentialMat(ptsL, ptsR, K, FM_RANSAC, 0.99, 1.0, inliers)
+// at /root/reference/main.cpp:224 (OpenCV's RANSACPointSetRegistrator with
+// the five-point callback), and its findFundamentalMat counterpart.
+//
+// Every floating-point result that decides an inlier is produced by the same
+// sequence of IEEE double operations a sequential CPU implementation would
+// use: lanes split the work by OUTPUT element (each element's own operation
+// order is untouched), and this file is compiled with -ffp-contract=off so no
+// multiply-add is fused.
+#include <cfloat>
+
 #include "sfm_ctx.h"
-extern "C" {
-int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double*, const double*, int, const double*, int, double, double, int, int, const int32_t*, int, uint8_t*, double*, int32_t*, int32_t*, int32_t*)
-{ return ctx ? ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "not built yet") : SFM_GPU_ERR_ARG; }
-int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const*, const int32_t*, int, const sfm_gpu_match_params*, int32_t*, int32_t*, sfm_gpu_dmatch*, int)
-{ return ctx ? ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "not built yet") : SFM_GPU_ERR_ARG; }
+#include "ransac_dev.h"
+
+namespace sfm {
+
+namespace {
+
+// ---- monomial pair tables --------------------------------------------------
+// Polynomials in (x,y,z):  degree<=1 [x,y,z,1];  degree<=2
+// [x2,xy,xz,y2,yz,z2,x,y,z,1];  degree<=3 in Nister's elimination order
+// [x3,y3,x2y,xy2,x2z,x2,y2z,y2,xyz,xy, xz2,xz,x,yz2,yz,y,z3,z2,z,1].
+// P11[m] lists the (i,j) with mono1[i]*mono1[j] == mono2[m] in row-major
+// order, P21[m] the (i,j) with mono2[i]*mono1[j] == mono3[m].
+__device__ __constant__ const signed char P11N[10] = {1, 2, 2, 1, 2, 1, 2, 2, 2, 1};
+__device__ __constant__ const signed char P11[10][2][2] = {
+    {{0,0},{-1,-1}}, {{0,1},{1,0}}, {{0,2},{2,0}}, {{1,1},{-1,-1}}, {{1,2},{2,1}},
+    {{2,2},{-1,-1}}, {{0,3},{3,0}}, {{1,3},{3,1}}, {{2,3},{3,2}}, {{3,3},{-1,-1}}};
+__device__ __constant__ const signed char P21N[20] = {1, 1, 2, 2, 2, 2, 2, 2, 3, 3,
+                                                      2, 3, 2, 2, 3, 2, 1, 2, 2, 1};
+__device__ __constant__ const signed char P21[20][3][2] = {
+    {{0,0},{-1,-1},{-1,-1}}, {{3,1},{-1,-1},{-1,-1}}, {{0,1},{1,0},{-1,-1}}, {{1,1},{3,0},{-1,-1}},
+    {{0,2},{2,0},{-1,-1}},   {{0,3},{6,0},{-1,-1}},   {{3,2},{4,1},{-1,-1}}, {{3,3},{7,1},{-1,-1}},
+    {{1,2},{2,1},{4,0}},     {{1,3},{6,1},{7,0}},     {{2,2},{5,0},{-1,-1}}, {{2,3},{6,2},{8,0}},
+    {{6,3},{9,0},{-1,-1}},   {{4,2},{5,1},{-1,-1}},   {{4,3},{7,2},{8,1}},   {{7,3},{9,1},{-1,-1}},
+    {{5,2},{-1,-1},{-1,-1}}, {{5,3},{8,2},{-1,-1}},   {{8,3},{9,2},{-1,-1}}, {{9,3},{-1,-1},{-1,-1}}};
+
+// coefficient m of a*b, both degree<=1 in (x,y,z)
+__device__ __forceinline__ double mul11_coef(const double* a, const double* b, int m)
+{
+    double s = 0.0;
+    const int n = P11N[m];
+    for (int t = 0; t < n; ++t) s = s + a[P11[m][t][0]] * b[P11[m][t][1]];
+    return s;
 }
+// coefficient m of a*b, a degree<=2, b degree<=1
+__device__ __forceinline__ double mul21_coef(const double* a, const double* b, int m)
+{
+    double s = 0.0;
+    const int n = P21N[m];
+    for (int t = 0; t < n; ++t) s = s + a[P21[m][t][0]] * b[P21[m][t][1]];
+    return s;
+}
+// coefficient i of a*b, univariate, degrees na and nb
+__device__ __forceinline__ double pmul_coef(const double* a, int na, const double* b, int nb, int i)
+{
+    double s = 0.0;
+    for (int ia = 0; ia <= na; ++ia) {
+        const int ib = i - ia;
+        if (ib >= 0 && ib <= nb) s = s + a[ia] * b[ib];
+    }
+    return s;
+}
+
+__device__ __forceinline__ double horner(const double* c, int n, double x)
+{
+    double s = c[n];
+    for (int i = n - 1; i >= 0; --i) s = s * x + c[i];
+    return s;
+}
+
+// Newton with bisection safeguard to a fixed point; see the CPU statement of
+// the same iteration in oracle/ for the reasoning.
+__device__ double solve_bracket(const double* P, const double* dP, int n, double lo, double hi, bool lo_neg)
+{
+    double xl = lo_neg ? lo : hi;
+    double xh = lo_neg ? hi : lo;
+    double x = 0.5 * (lo + hi);
+    double dxold = fabs(hi - lo);
+    double dx = dxold;
+    double f = horner(P, n, x);
+    double df = horner(dP, n - 1, x);
+    for (int it = 0; it < 300; ++it) {
+        if (f == 0.0) return x;
+        if (f < 0.0) xl = x; else xh = x;
+        const bool bisect = (((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) ||
+                            (fabs(2.0 * f) > fabs(dxold * df));
+        dxold = dx;
+        double xn;
+        if (bisect) {
+            dx = 0.5 * (xh - xl);
+            xn = xl + dx;
+            if (xn == xl || xn == xh) return x;
+        } else {
+            dx = f / df;
+            xn = x - dx;
+            if (xn == x) return x;
+        }
+        x = xn;
+        f = horner(P, n, x);
+        df = horner(dP, n - 1, x);
+    }
+    return x;
+}
+
+// Per-wavefront workspace in LDS.
+struct SolveWs {
+    double Q[7 * 9];
+    double N[4 * 9];
+    double L[9][10];
+    double T[3][10];
+    double A[10][20];
+    double B[3][3][5];
+    double M[3][8];
+    double c[11];
+    double cn[11];
+    double D[11][11];
+    double prev[12];
+    double cur[12];
+    double roots[12];
+    int perm[9];
+    int has[12];
+};
+
+// Null space of the rows x 9 system in w.Q by Gauss-Jordan with complete
+// pivoting (first maximum in row-major scan).  Writes 9-rows basis vectors
+// into w.N.  One wavefront; returns false on a zero pivot.
+__device__ bool null_space_9(SolveWs& w, int rows, int lane)
+{
+    double* A = w.Q;
+    if (lane < 9) w.perm[lane] = lane;
+    __syncthreads();
+    for (int p = 0; p < rows; ++p) {
+        int bi = p, bj = p;
+        double best = -1.0;
+        for (int i = p; i < rows; ++i)
+            for (int j = p; j < 9; ++j) {
+                const double v = fabs(A[i * 9 + j]);
+                if (v > best) { best = v; bi = i; bj = j; }
+            }
+        if (!(best > 0.0)) return false;
+        __syncthreads();
+        if (bi != p && lane < 9) {
+            const double t = A[p * 9 + lane];
+            A[p * 9 + lane] = A[bi * 9 + lane];
+            A[bi * 9 + lane] = t;
+        }
+        __syncthreads();
+        if (bj != p) {
+            if (lane < rows) {
+                const double t = A[lane * 9 + p];
+                A[lane * 9 + p] = A[lane * 9 + bj];
+                A[lane * 9 + bj] = t;
+            }
+            if (lane == 63) {
+                const int t = w.perm[p];
+                w.perm[p] = w.perm[bj];
+                w.perm[bj] = t;
+            }
+        }
+        __syncthreads();
+        const double piv = A[p * 9 + p];
+        __syncthreads();
+        if (lane > p && lane < 9) A[p * 9 + lane] = A[p * 9 + lane] / piv;
+        __syncthreads();
+        if (lane < rows * 9) {
+            const int i = lane / 9, j = lane % 9;
+            if (i != p && j > p) A[i * 9 + j] = A[i * 9 + j] - A[i * 9 + p] * A[p * 9 + j];
+        }
+        __syncthreads();
+        if (lane < rows) A[lane * 9 + p] = (lane == p) ? 1.0 : 0.0;
+        __syncthreads();
+    }
+    const int nfree = 9 - rows;
+    if (lane < nfree * 9) {
+        const int k = lane / 9, jj = lane % 9;
+        double v;
+        if (jj < rows) v = -A[jj * 9 + rows + k];
+        else v = (jj == rows + k) ? 1.0 : 0.0;
+        w.N[k * 9 + w.perm[jj]] = v;
+    }
+    __syncthreads();
+    return true;
+}
+
+// All real roots, ascending, of w.c[0..n] (coefficient of z^i at index i).
+// Isolation by the roots of successive derivatives; intervals of one level are
+// solved by different lanes.  Result in w.roots, returns the count.
+__device__ int real_roots(SolveWs& w, int n, int lane)
+{
+    double cmax = 0.0;
+    for (int i = 0; i <= n; ++i) cmax = fmax(cmax, fabs(w.c[i]));
+    if (!(cmax > 0.0) || !(cmax <= DBL_MAX)) return 0;
+    __syncthreads();
+    if (lane <= n) w.cn[lane] = w.c[lane] / cmax;
+    __syncthreads();
+    while (n > 0 && w.cn[n] == 0.0) --n;
+    if (n == 0) return 0;
+    if (lane <= n) w.D[n][lane] = w.cn[lane];
+    __syncthreads();
+    for (int k = n; k > 1; --k) {
+        if (lane < k) w.D[k - 1][lane] = (double)(lane + 1) * w.D[k][lane + 1];
+        __syncthreads();
+    }
+    double B = 0.0;
+    for (int i = 0; i < n; ++i) B = fmax(B, fabs(w.cn[i] / w.cn[n]));
+    B = 1.0 + B;
+    if (!(B < 1e25)) B = 1e25;
+    if (lane == 0) w.prev[0] = -w.D[1][0] / w.D[1][1];
+    __syncthreads();
+    int mprev = 1;
+    if (n == 1) {
+        if (lane == 0) w.roots[0] = w.prev[0];
+        __syncthreads();
+        return 1;
+    }
+    for (int k = 2; k <= n; ++k) {
+        int has = 0;
+        double r = 0.0;
+        if (lane <= mprev) {
+            const int t = lane;
+            double lo = (t == 0) ? -B : w.prev[t - 1];
+            double hi = (t < mprev) ? w.prev[t] : B;
+            if (lo < -B) lo = -B;
+            if (lo > B) lo = B;
+            if (hi < -B) hi = -B;
+            if (hi > B) hi = B;
+            if (hi > lo) {
+                const double flo = horner(w.D[k], k, lo);
+                const double fhi = horner(w.D[k], k, hi);
+                if (flo == 0.0) {
+                    has = 1;
+                    r = lo;
+                } else if (fhi != 0.0 && ((flo < 0.0) != (fhi < 0.0))) {
+                    has = 1;
+                    r = solve_bracket(w.D[k], w.D[k - 1], k, lo, hi, flo < 0.0);
+                } else if (fhi == 0.0 && t == mprev) {
+                    has = 1;
+                    r = hi;
+                }
+            }
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(has != 0);
+        __syncthreads();
+        if (has) w.cur[__popcll(mask & ((1ull << lane) - 1ull))] = r;
+        __syncthreads();
+        mprev = __popcll(mask);
+        if (lane < mprev) w.prev[lane] = w.cur[lane];
+        __syncthreads();
+    }
+    if (lane < mprev) w.roots[lane] = w.prev[lane];
+    __syncthreads();
+    return mprev;
+}
+
+// Five-point essential matrix solver (Nister 2004), one wavefront.
+// x1s/x2s: the 5 normalised correspondences (uniform across the wave).
+// Writes up to 10 unit-Frobenius-norm models (row-major) to `models`, ascending
+// in the root z; returns their number (uniform).
+__device__ int five_point_wave(SolveWs& w, const double* x1s, const double* x2s, double* models, int lane)
+{
+    if (lane < 45) {
+        const int i = lane / 9, j = lane % 9;
+        const double u1 = x1s[2 * i], v1 = x1s[2 * i + 1], u2 = x2s[2 * i], v2 = x2s[2 * i + 1];
+        double q;
+        switch (j) {
+            case 0: q = u2 * u1; break;
+            case 1: q = u2 * v1; break;
+            case 2: q = u2; break;
+            case 3: q = v2 * u1; break;
+            case 4: q = v2 * v1; break;
+            case 5: q = v2; break;
+            case 6: q = u1; break;
+            case 7: q = v1; break;
+            default: q = 1.0; break;
+        }
+        w.Q[lane] = q;
+    }
+    __syncthreads();
+    if (!null_space_9(w, 5, lane)) return 0;
+
+    // entry (r,c) of E = xX + yY + zZ + W as a degree-1 polynomial: gathered
+    // per use from N (e[r][c][k] = N[k*9 + 3r + c]).
+    auto load_e = [&](int r, int c, double* e) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = w.N[k * 9 + r * 3 + c];
+    };
+    // Lambda = E E^T - 0.5 tr(E E^T) I, upper triangle first
+    if (lane < 60) {
+        const int pair = lane / 10, m = lane % 10;
+        const int pi[6] = {0, 0, 0, 1, 1, 2}, pj[6] = {0, 1, 2, 1, 2, 2};
+        const int i = pi[pair], j = pj[pair];
+        double a[4], b[4];
+        load_e(i, 0, a); load_e(j, 0, b);
+        const double t0 = mul11_coef(a, b, m);
+        load_e(i, 1, a); load_e(j, 1, b);
+        const double t1 = mul11_coef(a, b, m);
+        load_e(i, 2, a); load_e(j, 2, b);
+        const double t2 = mul11_coef(a, b, m);
+        w.L[i * 3 + j][m] = (t0 + t1) + t2;
+    }
+    __syncthreads();
+    if (lane < 10) {
+        const int m = lane;
+        const double tr = (w.L[0][m] + w.L[4][m]) + w.L[8][m];
+        const double h = 0.5 * tr;
+        w.L[0][m] = w.L[0][m] - h;
+        w.L[4][m] = w.L[4][m] - h;
+        w.L[8][m] = w.L[8][m] - h;
+        w.L[3][m] = w.L[1][m];
+        w.L[6][m] = w.L[2][m];
+        w.L[7][m] = w.L[5][m];
+    }
+    __syncthreads();
+    for (int o = lane; o < 180; o += 64) {
+        const int row = o / 20, m = o % 20, i = row / 3, j = row % 3;
+        double b[4];
+        load_e(0, j, b);
+        const double t0 = mul21_coef(w.L[i * 3 + 0], b, m);
+        load_e(1, j, b);
+        const double t1 = mul21_coef(w.L[i * 3 + 1], b, m);
+        load_e(2, j, b);
+        const double t2 = mul21_coef(w.L[i * 3 + 2], b, m);
+        w.A[row][m] = (t0 + t1) + t2;
+    }
+    // determinant row: minors of rows 1,2 then expansion along row 0
+    if (lane < 30) {
+        const int which = lane / 10, m = lane % 10;
+        const int ca[3] = {1, 0, 0}, cb[3] = {2, 2, 1};
+        double a[4], b[4];
+        load_e(1, ca[which], a); load_e(2, cb[which], b);
+        const double p = mul11_coef(a, b, m);
+        load_e(1, cb[which], a); load_e(2, ca[which], b);
+        const double q = mul11_coef(a, b, m);
+        w.T[which][m] = p - q;
+    }
+    __syncthreads();
+    if (lane < 20) {
+        const int m = lane;
+        double b[4];
+        load_e(0, 0, b);
+        const double t0 = mul21_coef(w.T[0], b, m);
+        load_e(0, 1, b);
+        const double t1 = mul21_coef(w.T[1], b, m);
+        load_e(0, 2, b);
+        const double t2 = mul21_coef(w.T[2], b, m);
+        w.A[9][m] = (t0 - t1) + t2;
+    }
+    __syncthreads();
+
+    // Gauss-Jordan on the 10 leading columns, partial pivoting (first maximum)
+    for (int p = 0; p < 10; ++p) {
+        int bi = p;
+        double best = -1.0;
+        for (int i = p; i < 10; ++i) {
+            const double v = fabs(w.A[i][p]);
+            if (v > best) { best = v; bi = i; }
+        }
+        if (!(best > 0.0)) return 0;
+        __syncthreads();
+        if (bi != p && lane < 20) {
+            const double t = w.A[p][lane];
+            w.A[p][lane] = w.A[bi][lane];
+            w.A[bi][lane] = t;
+        }
+        __syncthreads();
+        const double piv = w.A[p][p];
+        __syncthreads();
+        if (lane > p && lane < 20) w.A[p][lane] = w.A[p][lane] / piv;
+        __syncthreads();
+        for (int o = lane; o < 200; o += 64) {
+            const int i = o / 20, j = o % 20;
+            if (i != p && j > p) w.A[i][j] = w.A[i][j] - w.A[i][p] * w.A[p][j];
+        }
+        __syncthreads();
+        if (lane < 10) w.A[lane][p] = (lane == p) ? 1.0 : 0.0;
+        __syncthreads();
+    }
+
+    // B(z): rows (e - z f), (g - z h), (i - z j) of the reduced system
+    if (lane < 9) {
+        const int r = lane / 3, v = lane % 3;
+        const double* hi = w.A[4 + 2 * r];
+        const double* lo = w.A[5 + 2 * r];
+        double* b = w.B[r][v];
+        if (v < 2) {
+            const int c0 = 10 + 3 * v;
+            b[0] = hi[c0 + 2];
+            b[1] = hi[c0 + 1] - lo[c0 + 2];
+            b[2] = hi[c0 + 0] - lo[c0 + 1];
+            b[3] = -lo[c0 + 0];
+            b[4] = 0.0;
+        } else {
+            b[0] = hi[19];
+            b[1] = hi[18] - lo[19];
+            b[2] = hi[17] - lo[18];
+            b[3] = hi[16] - lo[17];
+            b[4] = -lo[16];
+        }
+    }
+    __syncthreads();
+    // 2x2 minors of rows 1,2 (degrees 7,7,6), then det as degree-10 polynomial
+    if (lane < 24) {
+        const int which = lane / 8, i = lane % 8;
+        double v = 0.0;
+        if (which == 0) v = pmul_coef(w.B[1][1], 3, w.B[2][2], 4, i) - pmul_coef(w.B[1][2], 4, w.B[2][1], 3, i);
+        else if (which == 1) v = pmul_coef(w.B[1][0], 3, w.B[2][2], 4, i) - pmul_coef(w.B[1][2], 4, w.B[2][0], 3, i);
+        else if (i < 7) v = pmul_coef(w.B[1][0], 3, w.B[2][1], 3, i) - pmul_coef(w.B[1][1], 3, w.B[2][0], 3, i);
+        w.M[which][i] = v;
+    }
+    __syncthreads();
+    if (lane < 11) {
+        const int i = lane;
+        const double t0 = pmul_coef(w.B[0][0], 3, w.M[0], 7, i);
+        const double t1 = pmul_coef(w.B[0][1], 3, w.M[1], 7, i);
+        const double t2 = pmul_coef(w.B[0][2], 4, w.M[2], 6, i);
+        w.c[i] = (t0 - t1) + t2;
+    }
+    __syncthreads();
+    const int nr = real_roots(w, 10, lane);
+
+    bool ok = false;
+    double E[9];
+    if (lane < nr) {
+        const double z = w.roots[lane];
+        double b[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            b[r][0] = horner(w.B[r][0], 3, z);
+            b[r][1] = horner(w.B[r][1], 3, z);
+            b[r][2] = horner(w.B[r][2], 4, z);
+        }
+        double bn0 = 0, bn1 = 0, bn2 = 0, bestz = -1.0;
+        const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double* r0 = b[pr[q][0]];
+            const double* r1 = b[pr[q][1]];
+            const double nx = r0[1] * r1[2] - r0[2] * r1[1];
+            const double ny = r0[2] * r1[0] - r0[0] * r1[2];
+            const double nz = r0[0] * r1[1] - r0[1] * r1[0];
+            const double az = fabs(nz);
+            if (az > bestz) { bestz = az; bn0 = nx; bn1 = ny; bn2 = nz; }
+        }
+        const double nn = sqrt((bn0 * bn0 + bn1 * bn1) + bn2 * bn2);
+        if (nn > 0.0 && (bestz / nn >= 1e-10)) {
+            const double x = bn0 / bn2;
+            const double y = bn1 / bn2;
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                E[i] = ((x * w.N[i] + y * w.N[9 + i]) + z * w.N[18 + i]) + w.N[27 + i];
+                s = s + E[i] * E[i];
+            }
+            const double nrm = sqrt(s);
+            if (nrm > 0.0 && nrm <= DBL_MAX) {
+                ok = true;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) E[i] = E[i] / nrm;
+            }
+        }
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
+    if (ok) {
+        double* dst = models + 9 * __popcll(mask & ((1ull << lane) - 1ull));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dst[i] = E[i];
+    }
+    return __popcll(mask);
+}
+
+// Seven-point fundamental matrix solver on float32 pixel points, one
+// wavefront.  Up to 3 models, F33 = 1 when possible.
+__device__ int seven_point_wave(SolveWs& w, const float* m1, const float* m2, double* models, int lane)
+{
+    if (lane < 63) {
+        const int i = lane / 9, j = lane % 9;
+        const double x0 = m1[2 * i], y0 = m1[2 * i + 1], x1 = m2[2 * i], y1 = m2[2 * i + 1];
+        double q;
+        switch (j) {
+            case 0: q = x1 * x0; break;
+            case 1: q = x1 * y0; break;
+            case 2: q = x1; break;
+            case 3: q = y1 * x0; break;
+            case 4: q = y1 * y0; break;
+            case 5: q = y1; break;
+            case 6: q = x0; break;
+            case 7: q = y0; break;
+            default: q = 1.0; break;
+        }
+        w.Q[lane] = q;
+    }
+    __syncthreads();
+    if (!null_space_9(w, 7, lane)) return 0;
+    // f2 = N1, f1 = N0 - N1; entries of lambda*f1 + f2 as polynomials {f2, f1}
+    // stored in A[0][2i], A[0][2i+1]; f1, f2 kept in L[0], L[1]
+    if (lane < 9) {
+        const double f2 = w.N[9 + lane];
+        const double f1 = w.N[lane] - f2;
+        w.L[0][lane] = f1;
+        w.L[1][lane] = f2;
+        w.A[0][2 * lane] = f2;
+        w.A[0][2 * lane + 1] = f1;
+    }
+    __syncthreads();
+    const double* p = w.A[0];
+    if (lane < 9) {
+        const int which = lane / 3, i = lane % 3;
+        const int ia[3] = {4, 3, 3}, ib[3] = {8, 8, 7}, ic[3] = {5, 5, 4}, id[3] = {7, 6, 6};
+        w.M[which][i] = pmul_coef(p + 2 * ia[which], 1, p + 2 * ib[which], 1, i) -
+                        pmul_coef(p + 2 * ic[which], 1, p + 2 * id[which], 1, i);
+    }
+    __syncthreads();
+    if (lane < 4) {
+        const double t0 = pmul_coef(p + 0, 1, w.M[0], 2, lane);
+        const double t1 = pmul_coef(p + 2, 1, w.M[1], 2, lane);
+        const double t2 = pmul_coef(p + 4, 1, w.M[2], 2, lane);
+        w.c[lane] = (t0 - t1) + t2;
+    }
+    __syncthreads();
+    const int nr = real_roots(w, 3, lane);
+    if (lane < nr) {
+        const double* f1 = w.L[0];
+        const double* f2 = w.L[1];
+        double lambda = w.roots[lane], mu = 1.0;
+        const double s = f1[8] * lambda + f2[8];
+        double* F = models + 9 * lane;
+        if (fabs(s) > DBL_EPSILON) {
+            mu = 1.0 / s;
+            lambda = lambda * mu;
+            F[8] = 1.0;
+        } else {
+            F[8] = 0.0;
+        }
+        for (int i = 0; i < 8; ++i) F[i] = f1[i] * lambda + f2[i] * mu;
+    }
+    return nr;
+}
+
+// ---- error functions ---------------------------------------------------------
+
+// Sampson error test: (float)(s^2 / denom) <= tf, with the division skipped
+// when the outcome is certain (margins 2^-20 relative, far wider than any
+// rounding involved); identical result to always dividing.
+__device__ __forceinline__ int sampson_inlier(const double* E, double u1, double v1, double u2,
+                                              double v2, float tf, double tlo, double thi)
+{
+    const double Ex1_0 = (E[0] * u1 + E[1] * v1) + E[2];
+    const double Ex1_1 = (E[3] * u1 + E[4] * v1) + E[5];
+    const double Ex1_2 = (E[6] * u1 + E[7] * v1) + E[8];
+    const double Etx2_0 = (E[0] * u2 + E[3] * v2) + E[6];
+    const double Etx2_1 = (E[1] * u2 + E[4] * v2) + E[7];
+    const double s = (u2 * Ex1_0 + v2 * Ex1_1) + Ex1_2;
+    const double a = Ex1_0 * Ex1_0;
+    const double b = Ex1_1 * Ex1_1;
+    const double c = Etx2_0 * Etx2_0;
+    const double d = Etx2_1 * Etx2_1;
+    const double den = ((a + b) + c) + d;
+    const double s2 = s * s;
+    if (den > 0.0 && den <= DBL_MAX) {
+        if (s2 <= den * tlo) return 1;
+        if (s2 >= den * thi) return 0;
+    }
+    return (float)(s2 / den) <= tf ? 1 : 0;
+}
+
+__device__ __forceinline__ int symepi_inlier(const double* F, float fx1, float fy1, float fx2, float fy2, float tf)
+{
+    const double x1 = fx1, y1 = fy1, x2 = fx2, y2 = fy2;
+    double a = (F[0] * x1 + F[1] * y1) + F[2];
+    double b = (F[3] * x1 + F[4] * y1) + F[5];
+    double c = (F[6] * x1 + F[7] * y1) + F[8];
+    const double s2 = 1. / (a * a + b * b);
+    const double d2 = (x2 * a + y2 * b) + c;
+    a = (F[0] * x2 + F[3] * y2) + F[6];
+    b = (F[1] * x2 + F[4] * y2) + F[7];
+    c = (F[2] * x2 + F[5] * y2) + F[8];
+    const double s1 = 1. / (a * a + b * b);
+    const double d1 = (x1 * a + y1 * b) + c;
+    return (float)fmax(d1 * d1 * s1, d2 * d2 * s2) <= tf ? 1 : 0;
+}
+
+// ---- kernels -------------------------------------------------------------------
+
+// Normalises pixel coordinates for the essential model (x = (u-cx)/fx,
+// y = (v-cy)/fy) or narrows them to float32 for the fundamental model, as the
+// two OpenCV front ends do before RANSAC.  Also clears the per-problem result.
+__global__ void __launch_bounds__(256) ransac_prep_kernel(const RansacProb* __restrict__ probs)
+{
+    const RansacProb pb = probs[blockIdx.y];
+    const int n = *pb.n_ptr;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        pb.result[R_OK] = 0;
+        pb.result[R_HYP] = -1;
+        pb.result[R_Q] = -1;
+        pb.result[R_NINL] = 0;
+        pb.result[R_ITERS] = 0;
+        pb.result[R_VALID] = 0;
+        pb.result[R_DIRECT] = 0;
+        pb.result[R_N] = n;
+    }
+    if (i >= n) return;
+    if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
+        pb.x1[2 * i] = (pb.px1[2 * i] - pb.cx) / pb.fx;
+        pb.x1[2 * i + 1] = (pb.px1[2 * i + 1] - pb.cy) / pb.fy;
+        pb.x2[2 * i] = (pb.px2[2 * i] - pb.cx) / pb.fx;
+        pb.x2[2 * i + 1] = (pb.px2[2 * i + 1] - pb.cy) / pb.fy;
+    } else {
+        pb.f1[2 * i] = (float)pb.px1[2 * i];
+        pb.f1[2 * i + 1] = (float)pb.px1[2 * i + 1];
+        pb.f2[2 * i] = (float)pb.px2[2 * i];
+        pb.f2[2 * i + 1] = (float)pb.px2[2 * i + 1];
+    }
+}
+
+struct CvRng {
+    unsigned long long state;
+    __device__ unsigned next()
+    {
+        state = (unsigned long long)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
+        return (unsigned)state;
+    }
+    __device__ int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+__device__ bool have_collinear(const float* pts, const int* idx, int count)
+{
+    const int i = count - 1;
+    const float* pi = pts + 2 * idx[i];
+    for (int j = 0; j < i; ++j) {
+        const float* pj = pts + 2 * idx[j];
+        const double dx1 = pj[0] - pi[0];
+        const double dy1 = pj[1] - pi[1];
+        for (int k = 0; k < j; ++k) {
+            const float* pk = pts + 2 * idx[k];
+            const double dx2 = pk[0] - pi[0];
+            const double dy2 = pk[1] - pi[1];
+            if (fabs(dx2 * dy1 - dy2 * dx1) <=
+                FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2)))
+                return true;
+        }
+    }
+    return false;
+}
+
+// Sample table rows [row0, row0+nrows): m distinct uniform draws per row from
+// the cv::RNG stream seeded with 2^64-1, whole-subset redraw when the
+// fundamental-matrix collinearity check rejects it (at most 10000 attempts).
+// The stream is strictly sequential: one lane per problem; the generator
+// state is parked in the result block between calls.
+__global__ void __launch_bounds__(64) ransac_table_kernel(const RansacProb* __restrict__ probs, int row0, int nrows)
+{
+    if (threadIdx.x != 0) return;
+    const RansacProb pb = probs[blockIdx.x];
+    const int n = *pb.n_ptr;
+    const int m = pb.m;
+    if (n < m) return;
+    if (row0 > 0 && pb.result[R_VALID] < row0) return;  // stream ended earlier
+    if (n == m) {
+        if (row0 == 0) {
+            for (int i = 0; i < m; ++i) pb.table[i] = i;
+            pb.result[R_VALID] = 1;
+            pb.result[R_DIRECT] = 1;
+        }
+        return;
+    }
+    CvRng rng;
+    if (row0 == 0) rng.state = ~0ull;
+    else rng.state = ((unsigned long long)(unsigned)pb.result[R_RNG_HI] << 32) | (unsigned)pb.result[R_RNG_LO];
+    const bool check = pb.model == SFM_GPU_MODEL_FUNDAMENTAL;
+    int valid = row0;
+    for (int r = row0; r < row0 + nrows; ++r) {
+        int idx[7];
+        int iters = 0, i = 0;
+        for (; iters < 10000; ++iters) {
+            for (i = 0; i < m && iters < 10000;) {
+                int v;
+                for (;;) {
+                    v = idx[i] = rng.uniform(0, n);
+                    int j = 0;
+                    for (; j < i; ++j)
+                        if (v == idx[j]) break;
+                    if (j == i) break;
+                }
+                ++i;
+            }
+            if (i == m && check && (have_collinear(pb.f1, idx, m) || have_collinear(pb.f2, idx, m))) continue;
+            break;
+        }
+        if (!(i == m && iters < 10000)) break;
+        for (int k = 0; k < m; ++k) pb.table[(size_t)r * m + k] = idx[k];
+        valid = r + 1;
+    }
+    pb.result[R_VALID] = valid;
+    pb.result[R_RNG_HI] = (int)(unsigned)(rng.state >> 32);
+    pb.result[R_RNG_LO] = (int)(unsigned)rng.state;
+}
+
+// One wavefront per hypothesis.
+__global__ void __launch_bounds__(64) ransac_solve_kernel(const RansacProb* __restrict__ probs, int hyp0)
+{
+    __shared__ SolveWs ws;
+    __shared__ double sx1[14], sx2[14];
+    __shared__ float sf1[14], sf2[14];
+    const RansacProb pb = probs[blockIdx.y];
+    const int hyp = hyp0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    const int n = *pb.n_ptr;
+    const int m = pb.m;
+    if (n < m || hyp >= pb.result[R_VALID]) {
+        if (lane == 0) pb.nmodels[hyp] = 0;
+        return;
+    }
+    const int* row = pb.table + (size_t)hyp * m;
+    if (lane < 2 * m) {
+        const int pt = row[lane >> 1], comp = lane & 1;
+        if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
+            sx1[lane] = pb.x1[2 * pt + comp];
+            sx2[lane] = pb.x2[2 * pt + comp];
+        } else {
+            sf1[lane] = pb.f1[2 * pt + comp];
+            sf2[lane] = pb.f2[2 * pt + comp];
+        }
+    }
+    __syncthreads();
+    double* models = pb.models + (size_t)hyp * 90;
+    int nm;
+    if (pb.model == SFM_GPU_MODEL_ESSENTIAL) nm = five_point_wave(ws, sx1, sx2, models, lane);
+    else nm = seven_point_wave(ws, sf1, sf2, models, lane);
+    if (lane == 0) pb.nmodels[hyp] = nm;
+}
+
+// Inlier counts of every candidate model of one hypothesis over all points.
+__global__ void __launch_bounds__(256) ransac_score_kernel(const RansacProb* __restrict__ probs, int hyp0)
+{
+    __shared__ double sE[10][9];
+    __shared__ int sCnt[10];
+    const RansacProb pb = probs[blockIdx.y];
+    const int hyp = hyp0 + blockIdx.x;
+    const int n = *pb.n_ptr;
+    const int tid = threadIdx.x;
+    int nm = 0;
+    if (n >= pb.m && hyp < pb.result[R_VALID]) nm = pb.nmodels[hyp];
+    if (nm == 0) {
+        if (tid < 10) pb.counts[(size_t)hyp * 10 + tid] = -1;
+        return;
+    }
+    if (tid < nm * 9) sE[tid / 9][tid % 9] = pb.models[(size_t)hyp * 90 + tid];
+    if (tid < 10) sCnt[tid] = 0;
+    __syncthreads();
+    int cnt[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) cnt[q] = 0;
+    if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
+        const double2* X1 = (const double2*)pb.x1;
+        const double2* X2 = (const double2*)pb.x2;
+        for (int i = tid; i < n; i += 256) {
+            const double2 a = X1[i], b = X2[i];
+#pragma unroll
+            for (int q = 0; q < 10; ++q)
+                if (q < nm) cnt[q] += sampson_inlier(sE[q], a.x, a.y, b.x, b.y, pb.tf, pb.tlo, pb.thi);
+        }
+    } else {
+        const float2* X1 = (const float2*)pb.f1;
+        const float2* X2 = (const float2*)pb.f2;
+        for (int i = tid; i < n; i += 256) {
+            const float2 a = X1[i], b = X2[i];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (q < nm) cnt[q] += symepi_inlier(sE[q], a.x, a.y, b.x, b.y, pb.tf);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        if (q < nm) {
+            int v = cnt[q];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if ((tid & 63) == 0) atomicAdd(&sCnt[q], v);
+        }
+    }
+    __syncthreads();
+    if (tid < 10) pb.counts[(size_t)hyp * 10 + tid] = tid < nm ? sCnt[tid] : -1;
+}
+
+// Fixed-count winner: the first (hypothesis, model) in scan order whose count is
+// the maximum, provided it reaches m — what the sequential loop
+// `if (good > max(best, m-1))` ends with.
+__global__ void __launch_bounds__(1024) ransac_select_kernel(const RansacProb* __restrict__ probs, int n_hyp)
+{
+    __shared__ unsigned long long sh[16];
+    const RansacProb pb = probs[blockIdx.x];
+    const int n = *pb.n_ptr;
+    const int tid = threadIdx.x;
+    if (n < pb.m) return;
+    const int valid = min(n_hyp, pb.result[R_VALID]);
+    unsigned long long best = 0;
+    for (int e = tid; e < valid * 10; e += 1024) {
+        const int c = pb.counts[e];
+        if (c >= pb.m) {
+            const unsigned long long key = ((unsigned long long)(unsigned)c << 32) | (0xFFFFFFFFu - (unsigned)e);
+            best = key > best ? key : best;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    if ((tid & 63) == 0) sh[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 16; ++i) best = sh[i] > best ? sh[i] : best;
+        pb.result[R_ITERS] = valid;
+        if (pb.result[R_DIRECT]) {
+            const int ok = pb.nmodels[0] > 0;
+            pb.result[R_OK] = ok;
+            pb.result[R_HYP] = 0;
+            pb.result[R_Q] = 0;
+            pb.result[R_NINL] = ok ? n : 0;
+        } else if (best != 0) {
+            const unsigned e = 0xFFFFFFFFu - (unsigned)best;
+            pb.result[R_OK] = 1;
+            pb.result[R_HYP] = (int)(e / 10);
+            pb.result[R_Q] = (int)(e % 10);
+            pb.result[R_NINL] = (int)(best >> 32);
+        } else {
+            pb.result[R_OK] = 0;
+        }
+    }
+}
+
+// Inlier mask of the selected model (result[R_HYP], result[R_Q]) and a copy of
+// the model itself.  Leaves mask untouched when no model was found.
+__global__ void __launch_bounds__(256) ransac_mask_kernel(const RansacProb* __restrict__ probs)
+{
+    const RansacProb pb = probs[blockIdx.y];
+    const int n = *pb.n_ptr;
+    if (!pb.result[R_OK]) return;
+    const double* Mg = pb.models + (size_t)pb.result[R_HYP] * 90 + pb.result[R_Q] * 9;
+    double M[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M[i] = Mg[i];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 9) pb.model_out[i] = M[i];
+    if (i >= n) return;
+    int f;
+    if (pb.result[R_DIRECT]) {
+        f = 1;
+    } else if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
+        f = sampson_inlier(M, pb.x1[2 * i], pb.x1[2 * i + 1], pb.x2[2 * i], pb.x2[2 * i + 1], pb.tf,
+                           pb.tlo, pb.thi);
+    } else {
+        f = symepi_inlier(M, pb.f1[2 * i], pb.f1[2 * i + 1], pb.f2[2 * i], pb.f2[2 * i + 1], pb.tf);
+    }
+    pb.mask[i] = (uint8_t)f;
+}
+
+}  // namespace
+
+hipError_t launch_ransac_prep(hipStream_t s, const RansacProb* probs, int n_prob, int cap)
+{
+    hipLaunchKernelGGL(ransac_prep_kernel, dim3((cap + 255) / 256 > 0 ? (cap + 255) / 256 : 1, n_prob),
+                       dim3(256), 0, s, probs);
+    return hipGetLastError();
+}
+hipError_t launch_ransac_table(hipStream_t s, const RansacProb* probs, int n_prob, int row0, int nrows)
+{
+    hipLaunchKernelGGL(ransac_table_kernel, dim3(n_prob), dim3(64), 0, s, probs, row0, nrows);
+    return hipGetLastError();
+}
+hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int hyp0, int n_hyp)
+{
+    hipLaunchKernelGGL(ransac_solve_kernel, dim3(n_hyp, n_prob), dim3(64), 0, s, probs, hyp0);
+    return hipGetLastError();
+}
+hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int hyp0, int n_hyp)
+{
+    hipLaunchKernelGGL(ransac_score_kernel, dim3(n_hyp, n_prob), dim3(256), 0, s, probs, hyp0);
+    return hipGetLastError();
+}
+hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp)
+{
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(n_prob), dim3(1024), 0, s, probs, n_hyp);
+    return hipGetLastError();
+}
+hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap)
+{
+    hipLaunchKernelGGL(ransac_mask_kernel, dim3((cap + 255) / 256 > 0 ? (cap + 255) / 256 : 1, n_prob),
+                       dim3(256), 0, s, probs);
+    return hipGetLastError();
+}
+
+}  // namespace sfm

@@ -89,6 +89,13 @@ struct sfm_gpu_ctx {
     // match_pairs workspaces
     sfm::DevBuf mp_good, mp_pts, mp_ngood;
 
+    // device pointers of the last sfm_gpu_ransac call, for the test hooks
+    const int32_t* dbg_table = nullptr;
+    const int32_t* dbg_counts = nullptr;
+    const int32_t* dbg_nmodels = nullptr;
+    const double* dbg_models = nullptr;
+    int dbg_hyp_cap = 0, dbg_m = 0;
+
     bool profiling = false;
     std::map<std::string, sfm::KernelTimer> timers;
 

@@ -1,0 +1,117 @@
+"""End-to-end pair matching (kNN -> ratio -> RANSAC -> inlier matches) on the
+GPU against the same pipeline assembled from the CPU oracle."""
+import numpy as np
+import pytest
+
+from sfm_amd import matcher, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_images(n_img, n_desc, seed):
+    descs, kps = [], []
+    base = synth.sift_like(n_desc, seed)
+    rng = np.random.default_rng(seed)
+    for v in range(n_img):
+        descs.append(base.copy())
+        kps.append(None)
+    # chain: image v+1 holds noisy copies of 45% of image v's rows
+    out_d, out_k = [], []
+    Q = synth.sift_like(n_desc, seed)
+    for v in range(n_img):
+        out_d.append(Q)
+        Tn, Tnext, planted = synth.planted_pair(n_desc, n_desc, seed + 10 * v, seed + 10 * v + 1,
+                                                seed + 10 * v + 2, frac=0.45)
+        out_k.append((Tn, Tnext, planted))
+    return out_d, out_k
+
+
+def _oracle_pair(oracle, dq, dt, kq, kt, K, ratio, model, **kw):
+    m, c = oracle.knn_match(dq, dt, 2, nthreads=8)
+    keep = oracle.ratio_test(m, c, ratio)
+    good = m[keep, 0]
+    p1 = kq[good["queryIdx"]].astype(np.float64)
+    p2 = kt[good["trainIdx"]].astype(np.float64)
+    r = oracle.ransac(p1, p2, K, model=model, **kw)
+    sel = good[r["mask"].astype(bool)] if r["ok"] else good[:0]
+    return len(good), sel
+
+
+@pytest.mark.parametrize("mode", ["adaptive", "fixed"])
+def test_match_pairs_ring_like_reference(gpu_ctx, oracle, mode):
+    # three images in a ring, pairs (i, (i+1) % n) like main.cpp:167-173
+    n_img, n_desc = 3, 2500
+    descs, kps = [], []
+    for v in range(n_img):
+        descs.append(synth.sift_like(n_desc, 300 + v))
+    planted_all = []
+    rng = np.random.default_rng(5)
+    kps = [np.stack([rng.uniform(0, synth.IMG_W, n_desc), rng.uniform(0, synth.IMG_H, n_desc)],
+                    1).astype(np.float32) for _ in range(n_img)]
+    for v in range(n_img):
+        w = (v + 1) % n_img
+        rows_q = rng.permutation(n_desc)[:900]
+        rows_t = rng.permutation(n_desc)[:900]
+        if v == n_img - 1:
+            # do not overwrite rows of image 0 that pair 0 planted from
+            pass
+        noise = np.rint(rng.normal(0, 6, (900, 128)))
+        descs[w] = descs[w].copy()
+        descs[w][rows_t] = np.clip(descs[v][rows_q] + noise, 0, 255).astype(np.float32)
+        planted = np.full(n_desc, -1, np.int64)
+        planted[rows_q] = rows_t
+        kq, kt = synth.keypoints_for_pair(n_desc, n_desc, planted, 700 + v)
+        kps[v][rows_q] = kq[rows_q]
+        kps[w][rows_t] = kt[rows_t]
+    imgs = [matcher.Image(gpu_ctx, d, k) for d, k in zip(descs, kps)]
+    pairs = np.array([[i, (i + 1) % n_img] for i in range(n_img)], np.int32)
+    kw = dict(prob=0.99, threshold=1.0)
+    if mode == "fixed":
+        n_good, n_inl, sel = matcher.match_pairs(gpu_ctx, imgs, pairs, synth.REF_K, ratio=0.7,
+                                                 mode=matcher.RANSAC_FIXED, n_hyp=200,
+                                                 want_matches=True, **kw)
+        okw = dict(fixed_count=200, **kw)
+    else:
+        n_good, n_inl, sel = matcher.match_pairs(gpu_ctx, imgs, pairs, synth.REF_K, ratio=0.7,
+                                                 want_matches=True, **kw)
+        okw = dict(max_iters=1000, **kw)
+    for p, (i, j) in enumerate(pairs):
+        ng, osel = _oracle_pair(oracle, descs[i], descs[j], kps[i], kps[j], synth.REF_K, 0.7, 0, **okw)
+        assert n_good[p] == ng
+        assert n_inl[p] == len(osel)
+        assert (sel[p]["queryIdx"] == osel["queryIdx"]).all()
+        assert (sel[p]["trainIdx"] == osel["trainIdx"]).all()
+        assert (sel[p]["distance"].view(np.uint32) == osel["distance"].view(np.uint32)).all()
+        assert n_inl[p] > 200
+    for im in imgs:
+        im.close()
+
+
+def test_match_pairs_fundamental_and_ragged_sizes(gpu_ctx, oracle):
+    sizes = [1800, 700, 2300]
+    rng = np.random.default_rng(17)
+    descs = [synth.sift_like(n, 900 + i) for i, n in enumerate(sizes)]
+    kps = [np.stack([rng.uniform(0, synth.IMG_W, n), rng.uniform(0, synth.IMG_H, n)], 1).astype(np.float32)
+           for n in sizes]
+    # plant image0 -> image2 and image1 -> image2 overlaps
+    for (a, b, cnt, seed) in [(0, 2, 600, 1), (1, 2, 300, 2)]:
+        rq = rng.permutation(sizes[a])[:cnt]
+        rt = rng.permutation(sizes[b])[:cnt]
+        descs[b][rt] = np.clip(descs[a][rq] + np.rint(rng.normal(0, 6, (cnt, 128))), 0, 255).astype(np.float32)
+        planted = np.full(sizes[a], -1, np.int64)
+        planted[rq] = rt
+        kq, kt = synth.keypoints_for_pair(sizes[a], sizes[b], planted, 50 + seed)
+        kps[a][rq] = kq[rq]
+        kps[b][rt] = kt[rt]
+    imgs = [matcher.Image(gpu_ctx, d, k) for d, k in zip(descs, kps)]
+    pairs = np.array([[0, 2], [1, 2], [2, 1]], np.int32)
+    n_good, n_inl, sel = matcher.match_pairs(gpu_ctx, imgs, pairs, None, ratio=0.7,
+                                             model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED,
+                                             n_hyp=256, prob=0.99, threshold=3.0, want_matches=True)
+    for p, (i, j) in enumerate(pairs):
+        ng, osel = _oracle_pair(oracle, descs[i], descs[j], kps[i], kps[j], None, 0.7, 1,
+                                prob=0.99, threshold=3.0, fixed_count=256)
+        assert n_good[p] == ng and n_inl[p] == len(osel)
+        assert (sel[p]["trainIdx"] == osel["trainIdx"]).all()
+    for im in imgs:
+        im.close()

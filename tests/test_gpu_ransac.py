@@ -1,0 +1,143 @@
+"""GPU parity of the RANSAC path against the CPU oracle, through the C ABI.
+
+Bar: the sample table, the per-hypothesis inlier counts and the inlier mask are
+bit-exact; the model agrees to 1e-6 relative (in practice to the last bit,
+which the tests report).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from sfm_amd import matcher, synth
+from sfm_amd._lib import ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def _dump(ctx, n_hyp, m):
+    table = np.zeros((n_hyp, m), np.int32)
+    nmodels = np.zeros(n_hyp, np.int32)
+    counts = np.zeros((n_hyp, 10), np.int32)
+    models = np.zeros((n_hyp, 10, 3, 3), np.float64)
+    ctx.check(ctx._L.sfm_gpu_debug_ransac_dump(ctx.handle, n_hyp, ptr(table), ptr(nmodels),
+                                               ptr(counts), ptr(models)))
+    return table, nmodels, counts, models
+
+
+def _model_close(a, b, tol=1e-6):
+    return np.abs(a - b).max() <= tol * np.abs(b).max()
+
+
+@pytest.mark.parametrize("seed,n,frac", [(7, 3000, 0.9), (8, 600, 0.6), (9, 14000, 0.8)])
+def test_essential_fixed_counts_mask_model(gpu_ctx, oracle, seed, n, frac):
+    p1, p2, is_in, _ = synth.two_view(n, seed, inlier_frac=frac)
+    nh = 256
+    E, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, prob=0.99, threshold=1.0,
+                                          mode=matcher.RANSAC_FIXED, n_hyp=nh)
+    o = oracle.ransac(p1, p2, synth.REF_K, prob=0.99, threshold=1.0, fixed_count=nh,
+                      want_counts=True)
+    table, nmodels, counts, models = _dump(gpu_ctx, nh, 5)
+    assert (table == oracle.sample_table(n, 5, nh)).all()
+    assert (counts == o["counts"]).all()
+    assert r["ok"] == o["ok"] == 1
+    assert r["n_inliers"] == o["n_inliers"] and r["iters"] == nh
+    assert (mask == o["mask"]).all()
+    assert _model_close(E, o["model"])
+    assert (E == o["model"]).all(), "model differs in the last bits"
+
+
+def test_five_point_models_bit_exact(gpu_ctx, oracle):
+    p1, p2, _, _ = synth.two_view(500, 3, inlier_frac=0.7)
+    nh = 128
+    matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, mode=matcher.RANSAC_FIXED, n_hyp=nh)
+    table, nmodels, counts, models = _dump(gpu_ctx, nh, 5)
+    x1, _ = oracle.normalize_points(p1, synth.REF_K, 1.0)
+    x2, _ = oracle.normalize_points(p2, synth.REF_K, 1.0)
+    total = 0
+    for h in range(nh):
+        om = oracle.five_point(x1[table[h]], x2[table[h]])
+        assert len(om) == nmodels[h], h
+        assert (models[h, :len(om)] == om).all(), h
+        total += len(om)
+    assert total > nh      # on average more than one candidate per hypothesis
+
+
+def test_essential_custom_sample_table(gpu_ctx, oracle):
+    p1, p2, _, _ = synth.two_view(2000, 5, inlier_frac=0.75)
+    rng = np.random.default_rng(1)
+    table = np.stack([rng.permutation(2000)[:5] for _ in range(300)]).astype(np.int32)
+    E, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, prob=0.99,
+                                          mode=matcher.RANSAC_FIXED, sample_table=table)
+    o = oracle.ransac(p1, p2, synth.REF_K, prob=0.99, fixed_count=300, sample_table=table)
+    assert r["ok"] == 1 and (mask == o["mask"]).all() and r["n_inliers"] == o["n_inliers"]
+    assert _model_close(E, o["model"])
+
+
+@pytest.mark.parametrize("seed,n,frac", [(11, 1500, 0.85), (12, 4000, 0.91), (13, 700, 0.45),
+                                         (14, 300, 0.25)])
+def test_essential_adaptive_matches_sequential_loop(gpu_ctx, oracle, seed, n, frac):
+    p1, p2, _, _ = synth.two_view(n, seed, inlier_frac=frac, noise_px=0.4)
+    E, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, prob=0.99, threshold=1.0)
+    o = oracle.ransac(p1, p2, synth.REF_K, prob=0.99, threshold=1.0)
+    assert r["ok"] == o["ok"]
+    assert r["iters"] == o["iters"]
+    assert r["n_inliers"] == o["n_inliers"]
+    assert (mask == o["mask"]).all()
+    if o["ok"]:
+        assert _model_close(E, o["model"])
+
+
+def test_essential_degenerate_sizes(gpu_ctx, oracle):
+    p1, p2, _, _ = synth.two_view(5, 1, inlier_frac=1.0, noise_px=0.0)
+    sentinel = np.full(4, 7, np.uint8)
+    E, mask, r = matcher.findEssentialMat(gpu_ctx, p1[:4], p2[:4], synth.REF_K, mask=sentinel)
+    assert E is None and mask.tolist() == [7, 7, 7, 7]
+    E, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, prob=0.99)
+    o = oracle.ransac(p1, p2, synth.REF_K, prob=0.99)
+    assert r["ok"] == o["ok"] == 1 and mask.tolist() == [1] * 5
+    assert _model_close(E, o["model"])
+    # collinear / repeated points: no crash, same verdict as the oracle
+    q1 = np.tile(p1[:1], (40, 1))
+    q2 = np.tile(p2[:1], (40, 1))
+    E, mask, r = matcher.findEssentialMat(gpu_ctx, q1, q2, synth.REF_K, prob=0.99, maxIters=50)
+    o = oracle.ransac(q1, q2, synth.REF_K, prob=0.99, max_iters=50)
+    assert r["ok"] == o["ok"] and (mask == o["mask"]).all()
+
+
+@pytest.mark.parametrize("seed,n", [(21, 3300), (22, 900)])
+def test_fundamental_fixed_and_adaptive(gpu_ctx, oracle, seed, n):
+    p1, p2, _, _ = synth.two_view(n, seed, inlier_frac=0.8)
+    nh = 512
+    F, mask, r = matcher.findFundamentalMat(gpu_ctx, p1, p2, ransacReprojThreshold=3.0,
+                                            confidence=0.99, mode=matcher.RANSAC_FIXED, n_hyp=nh)
+    o = oracle.ransac(p1, p2, None, model=1, prob=0.99, threshold=3.0, fixed_count=nh,
+                      want_counts=True)
+    table, nmodels, counts, models = _dump(gpu_ctx, nh, 7)
+    assert (table == oracle.sample_table_f(p1, p2, nh)).all()
+    assert (counts == o["counts"]).all()
+    assert r["ok"] == 1 and (mask == o["mask"]).all() and r["n_inliers"] == o["n_inliers"]
+    assert _model_close(F, o["model"])
+    F, mask, r = matcher.findFundamentalMat(gpu_ctx, p1, p2, ransacReprojThreshold=3.0,
+                                            confidence=0.99)
+    o = oracle.ransac(p1, p2, None, model=1, prob=0.99, threshold=3.0)
+    assert r["ok"] == o["ok"] == 1 and r["iters"] == o["iters"]
+    assert (mask == o["mask"]).all()
+    assert _model_close(F, o["model"])
+
+
+def test_full_size_4096_hyps_properties(gpu_ctx):
+    # full-size fixed-count run: the mask is reproducible, consistent with the
+    # returned model, and the inlier count is the maximum over what adaptive finds
+    p1, p2, is_in, E_true = synth.two_view(13700, 2101, inlier_frac=0.9)
+    E, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, prob=0.99,
+                                          mode=matcher.RANSAC_FIXED, n_hyp=4096)
+    E2, mask2, r2 = matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, prob=0.99,
+                                             mode=matcher.RANSAC_FIXED, n_hyp=4096)
+    assert (mask == mask2).all() and (E == E2).all()
+    assert r["n_inliers"] == int(mask.sum())
+    Ea, maska, ra = matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, prob=0.99)
+    assert r["n_inliers"] >= ra["n_inliers"]
+    assert (mask.astype(bool) & ~is_in).sum() < 30
+    assert abs(np.linalg.det(E)) < 1e-10
+    assert min(np.abs(E - E_true).max(), np.abs(E + E_true).max()) < 0.02
