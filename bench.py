@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the matching hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): image pairs of 8192 x 8192 synthetic SIFT
+descriptors; per pair  kNN(k=2) -> ratio test (0.7) -> fundamental-matrix
+RANSAC with 2048 hypotheses (fixed count) -> inlier selection.  One step
+processes a batch of independent pairs (--pairs-per-step, default 64) whose
+float32 descriptors and keypoints are already resident in HBM; the conversion
+to the int8 layout is inside the timed region.  With N > 1 every rank runs its
+own batch (pairs are independent units: weak scaling, no data-path collective);
+ranks synchronise with a barrier on both sides of the timed region and the
+slowest rank's time is used.
+
+Prints one JSON line (rank 0).  `roofline` prices the distance kernel
+(knn2_mfma) against the dense int8 MFMA peak; `cpu_baseline` is the CPU oracle
+timed on this host's cores on one full pair of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+INT8_DENSE_PEAK_TOPS = 5000.0  # MI355X dense int8 MFMA: 2x the bf16 rate (~2.5 PF)
+
+
+def make_pairs(n_pairs, n_desc, seed0):
+    from sfm_amd import synth
+    descs, kps = [], []
+    for p in range(n_pairs):
+        s = seed0 + 10 * p
+        Q, T, planted = synth.planted_pair(n_desc, n_desc, s + 1, s + 2, s + 3)
+        kq, kt = synth.keypoints_for_pair(n_desc, n_desc, planted, s + 4)
+        descs += [Q, T]
+        kps += [kq, kt]
+    return descs, kps
+
+
+def cpu_baseline(descs, kps, n_hyp, threads):
+    """CPU oracle on one full pair: kNN + ratio + F-RANSAC."""
+    from oracle import pyoracle as po
+    t0 = time.perf_counter()
+    m, c = po.knn_match(descs[0], descs[1], 2, nthreads=threads)
+    keep = po.ratio_test(m, c, 0.7)
+    good = m[keep, 0]
+    p1 = kps[0][good["queryIdx"]].astype(np.float64)
+    p2 = kps[1][good["trainIdx"]].astype(np.float64)
+    t1 = time.perf_counter()
+    r = po.ransac(p1, p2, None, model=po.MODEL_FUNDAMENTAL, prob=0.99, threshold=3.0,
+                  fixed_count=n_hyp)
+    t2 = time.perf_counter()
+    return dict(seconds=t2 - t0, knn_seconds=t1 - t0, ransac_seconds=t2 - t1, n_good=int(len(good)),
+                n_inliers=int(r["n_inliers"]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs-per-step", type=int, default=64)
+    ap.add_argument("--n-desc", type=int, default=8192)
+    ap.add_argument("--hyps", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sfm_amd import matcher
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B, n, nh = args.pairs_per_step, args.n_desc, args.hyps
+    descs, kps = make_pairs(B, n, 1000 + 100000 * rank)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        d_desc = torch.from_numpy(np.stack(descs)).cuda()          # [2B, n, 128] float32
+        d_kp = torch.from_numpy(np.stack(kps)).cuda()              # [2B, n, 2] float32
+        blk = matcher.image_packed_bytes(n)
+        d_packed = torch.empty((2 * B, blk), dtype=torch.uint8, device="cuda")
+    stream.synchronize()
+    ctx = matcher.Context(local_rank, stream=stream.cuda_stream)
+    desc_ptrs = [d_desc[i].data_ptr() for i in range(2 * B)]
+    kp_ptrs = [d_kp[i].data_ptr() for i in range(2 * B)]
+    packed_ptrs = [d_packed[i].data_ptr() for i in range(2 * B)]
+    images = [matcher.WrappedImage(ctx, packed_ptrs[i], n) for i in range(2 * B)]
+    pairs = np.array([[2 * p, 2 * p + 1] for p in range(B)], np.int32)
+
+    def step():
+        matcher.prepare_many(ctx, desc_ptrs, [n] * (2 * B), n_desc_step, matcher.DESC_F32, kp_ptrs,
+                             packed_ptrs)
+        return matcher.match_pairs(ctx, images, pairs, None, ratio=0.7,
+                                   model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED,
+                                   prob=0.99, threshold=3.0, n_hyp=nh)
+
+    n_desc_step = 128 * 4
+    for _ in range(args.warmup):
+        n_good, n_inl = step()
+    matcher.check_inputs(ctx)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_good, n_inl = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern = {}
+    for name in ("prep_rows", "knn2_mfma", "knn_finalize", "knn_redo", "ratio_compact", "ransac_prep",
+                 "ransac_table", "ransac_solve", "ransac_score", "ransac_select", "ransac_mask",
+                 "inlier_compact"):
+        ms, cnt = ctx.profile_query(name)
+        if cnt:
+            kern[name] = {"avg_us": round(ms / cnt * 1e3, 2), "launches": cnt}
+    ctx.profile_enable(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_pairs = B * args.steps * world
+        value = total_pairs / elapsed
+        knn = kern.get("knn2_mfma", {"avg_us": float("nan"), "launches": 0})
+        ops_per_launch = 2.0 * n * n * 128 * B
+        achieved = ops_per_launch / (knn["avg_us"] * 1e-6) / 1e12
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_knn2_mfma.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                if pmc.get("pairs_per_launch") == B and pmc.get("n_desc") == n:
+                    traffic = pmc.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "matched image pairs/sec (8k x 8k SIFT, k=2+RANSAC)",
+            "value": round(value, 2),
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int8 MFMA / int32 accumulate (kNN), f64 (RANSAC)",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: pairs of %dx%d SIFT-like descriptors, kNN k=2 + ratio 0.7 + "
+                            "fundamental RANSAC %d hyps (fixed count)" % (n, n, nh),
+                "pairs_per_step": B,
+                "pairs_per_gpu_per_step": B,
+                "n_good_mean": float(np.mean(n_good)),
+                "n_inliers_mean": float(np.mean(n_inl)),
+            },
+            "roofline": {
+                "kernel": "knn2_mfma",
+                "bound": "mfma",
+                "achieved": round(achieved, 1),
+                "peak": INT8_DENSE_PEAK_TOPS,
+                "unit": "TFLOP/s",
+                "unit_note": "int8 multiply-add counted as 2 ops (TOP/s); peak = dense int8 MFMA",
+                "frac": round(achieved / INT8_DENSE_PEAK_TOPS, 4),
+                "traffic": traffic,
+                "ops_per_launch": ops_per_launch,
+                "avg_launch_us": knn["avg_us"],
+            },
+            "kernels": kern,
+        }
+        if not args.no_cpu_baseline:
+            threads = int(os.environ.get("OMP_NUM_THREADS", "8"))
+            threads = max(1, min(threads, 64))
+            cb = cpu_baseline(descs, kps, nh, threads)
+            out["cpu_baseline"] = {
+                "value": round(1.0 / cb["seconds"], 4),
+                "unit": "pairs/s",
+                "cores": threads,
+                "kind": "port",
+                "sample": "1 full pair (8192x8192 kNN on %d threads + ratio + F-RANSAC %d hyps on 1 "
+                          "thread): %.2f s kNN, %.2f s RANSAC" % (threads, nh, cb["knn_seconds"],
+                                                                   cb["ransac_seconds"]),
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    for im in images:
+        im.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,6 +150,35 @@ void sfm_gpu_image_destroy(sfm_gpu_ctx* ctx, sfm_gpu_image* img);
 int sfm_gpu_image_rows(const sfm_gpu_image* img);
 
 /*
+ * The same preparation into caller-owned device memory, for callers that keep
+ * many images in one allocation and exchange them between GPUs (the
+ * all-gather of the exhaustive matcher moves these blocks as they are).
+ *   sfm_gpu_image_packed_bytes(n)   size of the block for n rows
+ *   sfm_gpu_image_prepare_into      enqueues conversion of descriptors[i]
+ *                                   (main.cpp:175) into `packed_dev`; returns
+ *                                   without waiting; value validation is
+ *                                   reported by sfm_gpu_check_inputs
+ *   sfm_gpu_image_wrap              non-owning image handle over such a block
+ *   sfm_gpu_check_inputs            waits for the stream; SFM_GPU_ERR_NOT_U8 if
+ *                                   any block prepared since the last check
+ *                                   held a value outside the integers 0..255
+ * The block layout is position independent (offsets only), so a block may be
+ * copied to another GPU and wrapped there.
+ */
+size_t sfm_gpu_image_packed_bytes(int n);
+int sfm_gpu_image_prepare_into(sfm_gpu_ctx* ctx, const void* desc, int n, size_t step, int dim,
+                               int dtype, const float* keypoints_xy, int desc_on_device,
+                               void* packed_dev);
+/* sfm_gpu_image_prepare_into for `count` images already in device memory, in
+ * one launch (all arrays are host arrays of device pointers / sizes). */
+int sfm_gpu_image_prepare_many(sfm_gpu_ctx* ctx, const void* const* desc_dev, const int32_t* n,
+                               size_t step, int dim, int dtype, const float* const* keypoints_dev,
+                               void* const* packed_dev, int count);
+int sfm_gpu_image_wrap(sfm_gpu_ctx* ctx, const void* packed_dev, int n, int has_keypoints,
+                       sfm_gpu_image** out);
+int sfm_gpu_check_inputs(sfm_gpu_ctx* ctx);
+
+/*
  * knnMatch (main.cpp:184) between two prepared images.  matches/counts are
  * host pointers, or device pointers when out_on_device != 0 (then the call
  * only enqueues work on the context's stream).

@@ -73,6 +73,13 @@ def lib():
     L.sfm_gpu_image_destroy.argtypes = [vp, vp]
     L.sfm_gpu_image_destroy.restype = None
     L.sfm_gpu_image_rows.argtypes = [vp]
+    L.sfm_gpu_image_packed_bytes.argtypes = [c.c_int]
+    L.sfm_gpu_image_packed_bytes.restype = c.c_size_t
+    L.sfm_gpu_image_prepare_into.argtypes = [vp, vp, c.c_int, c.c_size_t, c.c_int, c.c_int, vp,
+                                             c.c_int, vp]
+    L.sfm_gpu_image_prepare_many.argtypes = [vp, vp, vp, c.c_size_t, c.c_int, c.c_int, vp, vp, c.c_int]
+    L.sfm_gpu_image_wrap.argtypes = [vp, vp, c.c_int, c.c_int, c.POINTER(vp)]
+    L.sfm_gpu_check_inputs.argtypes = [vp]
     L.sfm_gpu_knn_match_images.argtypes = [vp, vp, vp, c.c_int, vp, vp, c.c_int]
     L.sfm_gpu_match_pairs.argtypes = [vp, vp, vp, c.c_int, c.POINTER(MatchParams), vp, vp, vp,
                                       c.c_int]

@@ -37,9 +37,13 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t p)
 // One wave per row: converts 128 values to int8 (v - 128), validates them and
 // writes the per-row constants.  Rows n..rows_alloc-1 are written as padding.
 template <int DTYPE>
-__global__ void __launch_bounds__(256) prep_rows_kernel(const unsigned char* src, size_t step, int n,
-                                                        ImageDev img, int32_t* err_flag)
+__global__ void __launch_bounds__(256) prep_rows_kernel(const PrepJob* __restrict__ jobs, int32_t* err_flag)
 {
+    const PrepJob job = jobs[blockIdx.y];
+    const ImageDev img = job.img;
+    const unsigned char* src = job.src;
+    const size_t step = job.step;
+    const int n = img.n;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= img.rows_alloc) return;
@@ -78,6 +82,7 @@ __global__ void __launch_bounds__(256) prep_rows_kernel(const unsigned char* src
             img.qn[row] = n2;
             img.cin[row] = (tn >> 1) + KEY_OFFSET;  // arithmetic shift = floor
             img.low[row] = ((tn & 1) << 8) | (row & 255);
+            if (job.kp_src && img.kp) img.kp[row] = job.kp_src[row];
         } else {
             img.qn[row] = 0;
             img.cin[row] = PAD_CIN;
@@ -407,16 +412,14 @@ __global__ void __launch_bounds__(64) mfma_layout_probe_kernel(const int8_t* A, 
 
 // ---------------------------------------------------------------- hosts ----
 
-hipError_t launch_prep_rows(hipStream_t s, const void* src, size_t step, int dtype, int n,
-                            const ImageDev& img, int32_t* err_flag)
+hipError_t launch_prep_rows(hipStream_t s, const PrepJob* jobs_dev, int n_jobs, int rows_alloc_max,
+                            int dtype, int32_t* err_flag)
 {
-    const int blocks = (img.rows_alloc + 3) / 4;
+    const dim3 grid((rows_alloc_max + 3) / 4, n_jobs);
     if (dtype == SFM_GPU_DESC_F32)
-        hipLaunchKernelGGL(prep_rows_kernel<SFM_GPU_DESC_F32>, dim3(blocks), dim3(256), 0, s,
-                           (const unsigned char*)src, step, n, img, err_flag);
+        hipLaunchKernelGGL(prep_rows_kernel<SFM_GPU_DESC_F32>, grid, dim3(256), 0, s, jobs_dev, err_flag);
     else
-        hipLaunchKernelGGL(prep_rows_kernel<SFM_GPU_DESC_U8>, dim3(blocks), dim3(256), 0, s,
-                           (const unsigned char*)src, step, n, img, err_flag);
+        hipLaunchKernelGGL(prep_rows_kernel<SFM_GPU_DESC_U8>, grid, dim3(256), 0, s, jobs_dev, err_flag);
     return hipGetLastError();
 }
 

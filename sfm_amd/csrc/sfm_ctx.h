@@ -39,6 +39,24 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// Bytes of the device block that holds an image of n rows:
+// [desc rows*128 | cin rows*4 | low rows*4 | qn rows*4 | keypoints rows*8].
+inline int image_rows_alloc(int n) { return ((n > 0 ? n : 1) + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN; }
+inline size_t image_block_bytes(int n) { return (size_t)image_rows_alloc(n) * (DIM + 12 + 8); }
+inline ImageDev image_layout(void* base, int n)
+{
+    ImageDev d;
+    const int rows = image_rows_alloc(n);
+    d.n = n;
+    d.rows_alloc = rows;
+    d.desc = (int8_t*)base;
+    d.cin = (int32_t*)(d.desc + (size_t)rows * DIM);
+    d.low = d.cin + rows;
+    d.qn = d.low + rows;
+    d.kp = (float2*)(d.qn + rows);
+    return d;
+}
+
 // Device image whose storage is one DevBuf (used for the temporaries of the
 // host-pointer entry points and for sfm_gpu_image).
 struct ImageStore {
@@ -83,7 +101,7 @@ struct sfm_gpu_ctx {
 
     sfm::DevBuf raw_q, raw_t;
     sfm::ImageStore tmp_q, tmp_t;
-    sfm::DevBuf partial, out, counts, redo, jobs, flags;
+    sfm::DevBuf partial, out, counts, redo, jobs, flags, prepjobs;
     // ransac workspaces
     sfm::DevBuf rs_pts, rs_table, rs_models, rs_counts, rs_mask, rs_misc;
     // match_pairs workspaces
@@ -142,12 +160,5 @@ struct ProfScope {
                                "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
                                __FILE__, __LINE__);                                        \
     } while (0)
-
-// implemented in ransac_kernels.hip / ransac_host.cpp
-int ransac_run(sfm_gpu_ctx* ctx, const double* pts1_dev_px, const double* pts2_dev_px, int n,
-               const int32_t* n_dev, const double* K, int model, double prob, double threshold_px,
-               int max_iters, int mode, const int32_t* sample_table_host, int n_hyp,
-               uint8_t* mask_host, double* model_out, int32_t* n_inliers, int32_t* iters_used,
-               int32_t* ok);
 
 }  // namespace sfm

@@ -1,5 +1,7 @@
 // C ABI of libsfm_gpu: context, image preparation, k-NN matching entry points.
+#include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "sfm_ctx.h"
 
@@ -25,6 +27,21 @@ int check_knn_args(sfm_gpu_ctx* ctx, int n_query, int n_train, int dim, int dtyp
     return SFM_GPU_OK;
 }
 
+// Enqueues the preparation kernel for a batch of images.
+int run_prep_jobs(sfm_gpu_ctx* ctx, const std::vector<PrepJob>& jobs, int dtype, int flag_slot)
+{
+    if (jobs.empty()) return SFM_GPU_OK;
+    int rows_max = 0;
+    for (const PrepJob& j : jobs) rows_max = std::max(rows_max, j.img.rows_alloc);
+    SFM_HIP(ctx, ctx->prepjobs.reserve(sizeof(PrepJob) * jobs.size()));
+    SFM_HIP(ctx, hipMemcpyAsync(ctx->prepjobs.p, jobs.data(), sizeof(PrepJob) * jobs.size(),
+                                hipMemcpyHostToDevice, ctx->stream));
+    ProfScope ps(ctx, "prep_rows");
+    SFM_HIP(ctx, launch_prep_rows(ctx->stream, ctx->prepjobs.as<PrepJob>(), (int)jobs.size(), rows_max,
+                                  dtype, ctx->flags.as<int32_t>() + flag_slot));
+    return SFM_GPU_OK;
+}
+
 // Uploads (or reads in place) n rows and runs the preparation kernel into st.
 int prepare_image(sfm_gpu_ctx* ctx, ImageStore& st, DevBuf& raw, const void* desc, int n,
                   size_t step, int dtype, bool on_device, bool with_kp)
@@ -41,11 +58,15 @@ int prepare_image(sfm_gpu_ctx* ctx, ImageStore& st, DevBuf& raw, const void* des
         src = raw.p;
         src_step = rowbytes;
     }
-    SFM_HIP(ctx, ctx->flags.reserve(64));
-    {
-        ProfScope ps(ctx, "prep_rows");
-        SFM_HIP(ctx, launch_prep_rows(ctx->stream, src, src_step, dtype, n, st.d, ctx->flags.as<int32_t>()));
-    }
+    std::vector<PrepJob> jobs(1);
+    jobs[0].src = (const unsigned char*)src;
+    jobs[0].step = src_step;
+    jobs[0].kp_src = nullptr;
+    jobs[0].img = st.d;
+    // the job array buffer is reused by the next call: order it behind this one
+    int rc = run_prep_jobs(ctx, jobs, dtype, 0);
+    if (rc) return rc;
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SFM_GPU_OK;
 }
 
@@ -267,6 +288,94 @@ int sfm_gpu_knn_match_images(sfm_gpu_ctx* ctx, const sfm_gpu_image* query, const
     if (query->d.n > 0 && (!matches || !counts)) return ctx->fail(SFM_GPU_ERR_ARG, "null output pointer");
     SFM_HIP(ctx, hipSetDevice(ctx->device));
     return knn_on_images(ctx, query->d, train->d, k, matches, counts, out_on_device != 0);
+}
+
+size_t sfm_gpu_image_packed_bytes(int n) { return n < 0 ? 0 : image_block_bytes(n); }
+
+int sfm_gpu_image_prepare_into(sfm_gpu_ctx* ctx, const void* desc, int n, size_t step, int dim,
+                               int dtype, const float* keypoints_xy, int desc_on_device,
+                               void* packed_dev)
+{
+    if (!ctx || !packed_dev) return SFM_GPU_ERR_ARG;
+    int rc = check_knn_args(ctx, n, 0, dim, dtype, 2);
+    if (rc) return rc;
+    if (n >= (1 << 18)) return ctx->fail(SFM_GPU_ERR_TOO_MANY, "image rows %d >= 2^18", n);
+    if (n > 0 && !desc) return ctx->fail(SFM_GPU_ERR_ARG, "null descriptor pointer");
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    const ImageDev d = image_layout(packed_dev, n);
+    const size_t rowbytes = dtype == SFM_GPU_DESC_F32 ? DIM * 4 : DIM;
+    if (n > 0 && step < rowbytes) return ctx->fail(SFM_GPU_ERR_ARG, "row step %zu < row bytes", step);
+    const void* src = desc;
+    size_t src_step = step;
+    if (!desc_on_device && n > 0) {
+        // staging buffer is reused: wait for earlier users of it
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SFM_HIP(ctx, ctx->raw_q.reserve((size_t)n * rowbytes));
+        SFM_HIP(ctx, hipMemcpy2DAsync(ctx->raw_q.p, rowbytes, desc, step, rowbytes, n,
+                                      hipMemcpyHostToDevice, ctx->stream));
+        src = ctx->raw_q.p;
+        src_step = rowbytes;
+    }
+    std::vector<PrepJob> jobs(1);
+    jobs[0].src = (const unsigned char*)src;
+    jobs[0].step = src_step;
+    jobs[0].kp_src = (desc_on_device && keypoints_xy) ? (const float2*)keypoints_xy : nullptr;
+    jobs[0].img = d;
+    rc = run_prep_jobs(ctx, jobs, dtype, 1);
+    if (rc) return rc;
+    if (keypoints_xy && n > 0 && !desc_on_device)
+        SFM_HIP(ctx, hipMemcpyAsync(d.kp, keypoints_xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice,
+                                    ctx->stream));
+    if (!desc_on_device) SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_image_prepare_many(sfm_gpu_ctx* ctx, const void* const* desc_dev, const int32_t* n,
+                               size_t step, int dim, int dtype, const float* const* keypoints_dev,
+                               void* const* packed_dev, int count)
+{
+    if (!ctx || count < 0 || (count > 0 && (!desc_dev || !n || !packed_dev)))
+        return ctx ? ctx->fail(SFM_GPU_ERR_ARG, "null pointer or negative count") : SFM_GPU_ERR_ARG;
+    if (count == 0) return SFM_GPU_OK;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t rowbytes = dtype == SFM_GPU_DESC_F32 ? DIM * 4 : DIM;
+    if (step < rowbytes) return ctx->fail(SFM_GPU_ERR_ARG, "row step %zu < row bytes", step);
+    std::vector<PrepJob> jobs(count);
+    for (int i = 0; i < count; ++i) {
+        int rc = check_knn_args(ctx, n[i], 0, dim, dtype, 2);
+        if (rc) return rc;
+        if (n[i] >= (1 << 18)) return ctx->fail(SFM_GPU_ERR_TOO_MANY, "image rows %d >= 2^18", n[i]);
+        if ((n[i] > 0 && !desc_dev[i]) || !packed_dev[i])
+            return ctx->fail(SFM_GPU_ERR_ARG, "null pointer for image %d", i);
+        jobs[i].src = (const unsigned char*)desc_dev[i];
+        jobs[i].step = step;
+        jobs[i].kp_src = keypoints_dev ? (const float2*)keypoints_dev[i] : nullptr;
+        jobs[i].img = image_layout(packed_dev[i], n[i]);
+    }
+    return run_prep_jobs(ctx, jobs, dtype, 1);
+}
+
+int sfm_gpu_image_wrap(sfm_gpu_ctx* ctx, const void* packed_dev, int n, int has_keypoints,
+                       sfm_gpu_image** out)
+{
+    if (!ctx || !out || !packed_dev || n < 0) return SFM_GPU_ERR_ARG;
+    ImageHolder* h = new (std::nothrow) ImageHolder();
+    if (!h) return ctx->fail(SFM_GPU_ERR_NOMEM, "host allocation failed");
+    h->img.d = image_layout((void*)packed_dev, n);
+    if (!has_keypoints) h->img.d.kp = nullptr;
+    *out = &h->img;  // h->st owns nothing: destroy only frees the handle
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_check_inputs(sfm_gpu_ctx* ctx)
+{
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    int32_t flag = 0;
+    SFM_HIP(ctx, hipMemcpyAsync(&flag, ctx->flags.as<int32_t>() + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipMemsetAsync(ctx->flags.as<int32_t>() + 1, 0, 4, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (flag) return ctx->fail(SFM_GPU_ERR_NOT_U8, "descriptor values must be integers in 0..255");
+    return SFM_GPU_OK;
 }
 
 // ---- measurement ------------------------------------------------------

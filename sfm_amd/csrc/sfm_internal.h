@@ -45,6 +45,15 @@ struct ImageDev {
     float2* kp = nullptr;
 };
 
+// One image to convert: source rows (float32 or uint8, device memory),
+// optional keypoints to copy beside them, destination layout.
+struct PrepJob {
+    const unsigned char* src;
+    size_t step;
+    const float2* kp_src;
+    ImageDev img;
+};
+
 struct KnnJob {
     const int8_t* q_desc;
     const int8_t* t_desc;
@@ -77,8 +86,8 @@ struct sfm_gpu_image {
 // launchers implemented in knn_kernels.hip
 namespace sfm {
 
-hipError_t launch_prep_rows(hipStream_t s, const void* src, size_t step, int dtype, int n,
-                            const ImageDev& img, int32_t* err_flag);
+hipError_t launch_prep_rows(hipStream_t s, const PrepJob* jobs_dev, int n_jobs, int rows_alloc_max,
+                            int dtype, int32_t* err_flag);
 // Picks the workgroup shape and split count for a batch of equally sized jobs.
 struct KnnPlan {
     int n_splits;

@@ -259,3 +259,50 @@ def match_pairs(ctx, images, pairs, K, ratio=0.7, model=MODEL_ESSENTIAL, mode=RA
     if want_matches:
         return n_good, n_inl, [out[i, :n_inl[i]].copy() for i in range(n_pairs)]
     return n_good, n_inl
+
+
+# ---- images in caller-owned device memory ---------------------------------
+
+def image_packed_bytes(n):
+    """Size in bytes of the device block that holds a prepared image of n rows."""
+    return int(_lib.lib().sfm_gpu_image_packed_bytes(int(n)))
+
+
+def prepare_many(ctx, desc_ptrs, ns, step, dtype, kp_ptrs, packed_ptrs):
+    """Converts `len(ns)` images that already sit in device memory into their
+    packed blocks with one launch (enqueue only).  All arguments are sequences
+    of device addresses (ints) / row counts."""
+    cnt = len(ns)
+    d = (ctypes.c_void_p * cnt)(*desc_ptrs)
+    p = (ctypes.c_void_p * cnt)(*packed_ptrs)
+    k = (ctypes.c_void_p * cnt)(*kp_ptrs) if kp_ptrs is not None else None
+    n = np.ascontiguousarray(ns, dtype=np.int32)
+    ctx.check(ctx._L.sfm_gpu_image_prepare_many(ctx.handle, d, ptr(n), step, 128, dtype, k, p, cnt))
+
+
+def check_inputs(ctx):
+    """Waits for the stream and raises if a prepared image held non-u8 values."""
+    ctx.check(ctx._L.sfm_gpu_check_inputs(ctx.handle))
+
+
+class WrappedImage:
+    """Non-owning image handle over a packed block in device memory."""
+
+    def __init__(self, ctx, packed_ptr, n, has_keypoints=True):
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        ctx.check(ctx._L.sfm_gpu_image_wrap(ctx.handle, ctypes.c_void_p(packed_ptr), n,
+                                            1 if has_keypoints else 0, ctypes.byref(h)))
+        self.handle = h
+        self.n = n
+
+    def close(self):
+        if self.handle and self.ctx.handle:
+            self.ctx._L.sfm_gpu_image_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
