@@ -120,7 +120,9 @@ int sfm_gpu_ratio_test(const sfm_gpu_dmatch* matches, const int32_t* counts, int
  *                 self-shortening loop; SFM_GPU_RANSAC_FIXED scores exactly
  *                 n_hyp hypotheses
  *   sample_table  host, optional n_hyp x m int32 point indices (m = 5 or 7),
- *                 FIXED mode only; NULL: the table OpenCV's RNG(-1) would draw
+ *                 FIXED mode only; NULL: the library's own seeded table, whose
+ *                 rows are independent draws of a counter-based generator
+ *                 (ADAPTIVE always uses the stream OpenCV's RNG(-1) draws)
  *   n_hyp         hypotheses in FIXED mode (ignored in ADAPTIVE)
  *   mask          out, n bytes 0/1; left untouched when *ok == 0
  *   model         out, 9 doubles row-major (E on normalised coordinates with

@@ -42,6 +42,8 @@ def lib():
         L.oracle_sample_table.restype = c.c_int
         L.oracle_sample_table_f.argtypes = [c.c_int, vp, vp, c.c_int, vp]
         L.oracle_sample_table_f.restype = c.c_int
+        L.oracle_sample_table_fixed.argtypes = [c.c_int, c.c_int, c.c_int, vp, vp, vp]
+        L.oracle_sample_table_fixed.restype = c.c_int
         L.oracle_ransac_update_num_iters.argtypes = [c.c_double, c.c_double, c.c_int, c.c_int]
         L.oracle_ransac_update_num_iters.restype = c.c_int
         L.oracle_real_roots.argtypes = [vp, c.c_int, vp]
@@ -116,6 +118,16 @@ def sample_table_f(pts1, pts2, n_iters):
     out = np.zeros((n_iters, 7), dtype=np.int32)
     got = lib().oracle_sample_table_f(pts1.shape[0], _p(pts1), _p(pts2), n_iters, _p(out))
     return out[:max(got, 0)]
+
+
+def sample_table_fixed(count, m, n_rows, pts1=None, pts2=None):
+    out = np.zeros((n_rows, m), dtype=np.int32)
+    if pts1 is not None:
+        pts1 = np.ascontiguousarray(pts1, dtype=np.float32)
+        pts2 = np.ascontiguousarray(pts2, dtype=np.float32)
+    rc = lib().oracle_sample_table_fixed(count, m, n_rows, _p(pts1), _p(pts2), _p(out))
+    assert rc == 0
+    return out
 
 
 def update_num_iters(p, ep, m, max_iters):

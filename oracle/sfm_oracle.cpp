@@ -572,6 +572,50 @@ bool get_subset(CvRng& rng, int count, int m, int* idx, const float* p1, const f
     return i == m && iters < max_attempts;
 }
 
+// Fixed-count mode sample table: every row is drawn independently of the others
+// from a counter-based generator (splitmix64 finaliser over row / slot / attempt
+// counters), so rows can be produced in any order or in parallel.  This mode is
+// a benchmark mode with no OpenCV counterpart; the adaptive mode keeps OpenCV's
+// sequential cv::RNG stream.
+const uint64_t FIXED_TABLE_SEED = 0x53464D5F5441424CULL;
+
+uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// index in [0,count) for (row, subset attempt u, slot i, slot attempt t)
+int fixed_draw(int count, uint32_t row, uint32_t u, uint32_t i, uint32_t t)
+{
+    uint64_t ctr = ((uint64_t)row << 32) | ((uint64_t)(u & 0xFF) << 24) | ((uint64_t)(i & 0xFF) << 16) |
+                   (uint64_t)(t & 0xFFFF);
+    uint64_t h = mix64(FIXED_TABLE_SEED + ctr * 0x9E3779B97F4A7C15ULL);
+    return (int)(((h >> 32) * (uint64_t)(uint32_t)count) >> 32);
+}
+
+// One row: m distinct indices; with points given, subsets failing the
+// fundamental-matrix collinearity check are redrawn (at most 64 times, then the
+// row is marked invalid by idx[0] = -1).
+void fixed_row(int count, int m, uint32_t row, const float* p1, const float* p2, int* idx)
+{
+    for (uint32_t u = 0; u < 64; u++) {
+        for (int i = 0; i < m; i++) {
+            for (uint32_t t = 0;; t++) {
+                int v = fixed_draw(count, row, u, (uint32_t)i, t);
+                int j = 0;
+                for (; j < i; j++)
+                    if (idx[j] == v) break;
+                if (j == i) { idx[i] = v; break; }
+            }
+        }
+        if (p1 && (have_collinear(p1, idx, m) || have_collinear(p2, idx, m))) continue;
+        return;
+    }
+    idx[0] = -1;
+}
+
 int cv_round(double v) { return (int)std::nearbyint(v); }
 
 int update_num_iters(double p, double ep, int model_points, int max_iters)
@@ -692,6 +736,14 @@ int oracle_sample_table_f(int count, const float* pts1, const float* pts2, int n
     return n_iters;
 }
 
+int oracle_sample_table_fixed(int count, int m, int n_rows, const float* pts1, const float* pts2,
+                              int32_t* out)
+{
+    if (count <= m || m <= 0 || m > 7) return -1;
+    for (int r = 0; r < n_rows; r++) fixed_row(count, m, (uint32_t)r, pts1, pts2, out + (size_t)r * m);
+    return 0;
+}
+
 int oracle_ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
 {
     return update_num_iters(p, ep, model_points, max_iters);
@@ -806,6 +858,9 @@ int oracle_ransac(int model_kind, const double* pts1, const double* pts2, int n,
         int idx[7];
         if (sample_table) {
             for (int i = 0; i < m; i++) idx[i] = sample_table[(size_t)iter * m + i];
+        } else if (fixed_count > 0) {
+            fixed_row(n, m, (uint32_t)iter, model_kind == 1 ? f1.data() : nullptr,
+                      model_kind == 1 ? f2.data() : nullptr, idx);
         } else {
             bool found = get_subset(rng, n, m, idx, model_kind == 1 ? f1.data() : nullptr,
                                     model_kind == 1 ? f2.data() : nullptr, 10000);
@@ -816,7 +871,7 @@ int oracle_ransac(int model_kind, const double* pts1, const double* pts2, int n,
         }
         if (hyp_counts)
             for (int q = 0; q < 10; q++) hyp_counts[(size_t)iter * 10 + q] = -1;
-        int nm = solve(idx, models);
+        int nm = idx[0] < 0 ? 0 : solve(idx, models);
         if (nm <= 0) continue;
         for (int q = 0; q < nm; q++) {
             errors(models + 9 * q);

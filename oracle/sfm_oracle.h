@@ -70,6 +70,13 @@ int oracle_sample_table(int count, int m, int n_iters, int32_t* out);
 int oracle_sample_table_f(int count, const float* pts1, const float* pts2,
                           int n_iters, int32_t* out);
 
+/* Sample table of the fixed-count mode: n_rows independent rows from the
+ * counter-based generator (no OpenCV counterpart).  pts1/pts2 (float32 pixels)
+ * enable the fundamental-matrix collinearity redraw; NULL for the essential
+ * model.  A row that cannot be drawn has out[row][0] = -1. */
+int oracle_sample_table_fixed(int count, int m, int n_rows, const float* pts1, const float* pts2,
+                              int32_t* out);
+
 int oracle_ransac_update_num_iters(double p, double ep, int model_points,
                                    int max_iters);
 
@@ -110,7 +117,8 @@ double oracle_normalize_points(const double* pts_px, int n, const double* K,
  *   fixed_count   0: OpenCV-adaptive loop (max_iters cap, niters shrinks);
  *                 >0: evaluate exactly that many hypotheses, no early stop
  *   sample_table  optional fixed_count*m (or max_iters*m) indices; NULL =>
- *                 generated from RNG(-1) like OpenCV
+ *                 adaptive: generated from RNG(-1) like OpenCV; fixed count:
+ *                 the counter-based table of oracle_sample_table_fixed
  *   mask          n bytes; untouched when the call fails (n < m)
  *   hyp_counts    optional [n_hyp][10] inlier counts (-1 = no such model),
  *                 filled for the hypotheses actually evaluated

@@ -139,7 +139,7 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             SFM_HIP(ctx, hipMemcpyAsync(probs[0].result + R_VALID, &valid, 4, hipMemcpyHostToDevice, s));
         } else {
             ProfScope ps(ctx, "ransac_table");
-            SFM_HIP(ctx, launch_ransac_table(s, dprobs, n_prob, 0, nh));
+            SFM_HIP(ctx, launch_ransac_table_fixed(s, dprobs, n_prob, nh));
         }
         {
             ProfScope ps(ctx, "ransac_solve");

@@ -630,24 +630,91 @@ struct CvRng {
     __device__ int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
 };
 
-__device__ bool have_collinear(const float* pts, const int* idx, int count)
+// OpenCV's subset check for the fundamental matrix: is the last point of the
+// subset (nearly) collinear with any two earlier ones.  p holds the subset's
+// points (x,y interleaved).
+__device__ bool have_collinear(const float* p, int count)
 {
     const int i = count - 1;
-    const float* pi = pts + 2 * idx[i];
     for (int j = 0; j < i; ++j) {
-        const float* pj = pts + 2 * idx[j];
-        const double dx1 = pj[0] - pi[0];
-        const double dy1 = pj[1] - pi[1];
+        const double dx1 = p[2 * j] - p[2 * i];
+        const double dy1 = p[2 * j + 1] - p[2 * i + 1];
         for (int k = 0; k < j; ++k) {
-            const float* pk = pts + 2 * idx[k];
-            const double dx2 = pk[0] - pi[0];
-            const double dy2 = pk[1] - pi[1];
+            const double dx2 = p[2 * k] - p[2 * i];
+            const double dy2 = p[2 * k + 1] - p[2 * i + 1];
             if (fabs(dx2 * dy1 - dy2 * dx1) <=
                 FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2)))
                 return true;
         }
     }
     return false;
+}
+
+__device__ bool subset_collinear(const RansacProb& pb, const int* idx, int m)
+{
+    float a[14], b[14];
+    for (int k = 0; k < m; ++k) {
+        const float2 u = ((const float2*)pb.f1)[idx[k]];
+        const float2 v = ((const float2*)pb.f2)[idx[k]];
+        a[2 * k] = u.x; a[2 * k + 1] = u.y;
+        b[2 * k] = v.x; b[2 * k + 1] = v.y;
+    }
+    return have_collinear(a, m) || have_collinear(b, m);
+}
+
+// Fixed-count mode: rows are independent draws of a counter-based generator
+// (splitmix64 finaliser over row / subset attempt / slot / slot attempt), one
+// thread per row.  No OpenCV counterpart; the adaptive mode below keeps
+// OpenCV's sequential stream.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ int fixed_draw(int count, unsigned row, unsigned u, unsigned i, unsigned t)
+{
+    const unsigned long long ctr = ((unsigned long long)row << 32) | ((unsigned long long)(u & 0xFF) << 24) |
+                                   ((unsigned long long)(i & 0xFF) << 16) | (unsigned long long)(t & 0xFFFF);
+    const unsigned long long h = mix64(0x53464D5F5441424CULL + ctr * 0x9E3779B97F4A7C15ULL);
+    return (int)(((h >> 32) * (unsigned long long)(unsigned)count) >> 32);
+}
+
+__global__ void __launch_bounds__(256) ransac_table_fixed_kernel(const RansacProb* __restrict__ probs, int nrows)
+{
+    const RansacProb pb = probs[blockIdx.y];
+    const int n = *pb.n_ptr;
+    const int m = pb.m;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (n < m) return;
+    if (n == m) {
+        if (r == 0) {
+            for (int i = 0; i < m; ++i) pb.table[i] = i;
+            pb.result[R_VALID] = 1;
+            pb.result[R_DIRECT] = 1;
+        }
+        return;
+    }
+    if (r == 0) pb.result[R_VALID] = nrows;
+    if (r >= nrows) return;
+    const bool check = pb.model == SFM_GPU_MODEL_FUNDAMENTAL;
+    int idx[7];
+    bool ok = false;
+    for (unsigned u = 0; u < 64 && !ok; ++u) {
+        for (int i = 0; i < m; ++i) {
+            for (unsigned t = 0;; ++t) {
+                const int v = fixed_draw(n, (unsigned)r, u, (unsigned)i, t);
+                int j = 0;
+                for (; j < i; ++j)
+                    if (idx[j] == v) break;
+                if (j == i) { idx[i] = v; break; }
+            }
+        }
+        ok = !(check && subset_collinear(pb, idx, m));
+    }
+    if (!ok) idx[0] = -1;
+    for (int k = 0; k < m; ++k) pb.table[(size_t)r * m + k] = idx[k];
 }
 
 // Sample table rows [row0, row0+nrows): m distinct uniform draws per row from
@@ -691,7 +758,7 @@ __global__ void __launch_bounds__(64) ransac_table_kernel(const RansacProb* __re
                 }
                 ++i;
             }
-            if (i == m && check && (have_collinear(pb.f1, idx, m) || have_collinear(pb.f2, idx, m))) continue;
+            if (i == m && check && subset_collinear(pb, idx, m)) continue;
             break;
         }
         if (!(i == m && iters < 10000)) break;
@@ -719,6 +786,10 @@ __global__ void __launch_bounds__(64) ransac_solve_kernel(const RansacProb* __re
         return;
     }
     const int* row = pb.table + (size_t)hyp * m;
+    if (row[0] < 0) {  // the row could not be drawn
+        if (lane == 0) pb.nmodels[hyp] = 0;
+        return;
+    }
     if (lane < 2 * m) {
         const int pt = row[lane >> 1], comp = lane & 1;
         if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
@@ -874,6 +945,11 @@ hipError_t launch_ransac_prep(hipStream_t s, const RansacProb* probs, int n_prob
 hipError_t launch_ransac_table(hipStream_t s, const RansacProb* probs, int n_prob, int row0, int nrows)
 {
     hipLaunchKernelGGL(ransac_table_kernel, dim3(n_prob), dim3(64), 0, s, probs, row0, nrows);
+    return hipGetLastError();
+}
+hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int n_prob, int nrows)
+{
+    hipLaunchKernelGGL(ransac_table_fixed_kernel, dim3((nrows + 255) / 256, n_prob), dim3(256), 0, s, probs, nrows);
     return hipGetLastError();
 }
 hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int hyp0, int n_hyp)

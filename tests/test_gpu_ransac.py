@@ -38,7 +38,7 @@ def test_essential_fixed_counts_mask_model(gpu_ctx, oracle, seed, n, frac):
     o = oracle.ransac(p1, p2, synth.REF_K, prob=0.99, threshold=1.0, fixed_count=nh,
                       want_counts=True)
     table, nmodels, counts, models = _dump(gpu_ctx, nh, 5)
-    assert (table == oracle.sample_table(n, 5, nh)).all()
+    assert (table == oracle.sample_table_fixed(n, 5, nh)).all()
     assert (counts == o["counts"]).all()
     assert r["ok"] == o["ok"] == 1
     assert r["n_inliers"] == o["n_inliers"] and r["iters"] == nh
@@ -65,8 +65,7 @@ def test_five_point_models_bit_exact(gpu_ctx, oracle):
 
 def test_essential_custom_sample_table(gpu_ctx, oracle):
     p1, p2, _, _ = synth.two_view(2000, 5, inlier_frac=0.75)
-    rng = np.random.default_rng(1)
-    table = np.stack([rng.permutation(2000)[:5] for _ in range(300)]).astype(np.int32)
+    table = oracle.sample_table(2000, 5, 300)      # the rows OpenCV's RNG(-1) draws
     E, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, prob=0.99,
                                           mode=matcher.RANSAC_FIXED, sample_table=table)
     o = oracle.ransac(p1, p2, synth.REF_K, prob=0.99, fixed_count=300, sample_table=table)
@@ -114,7 +113,7 @@ def test_fundamental_fixed_and_adaptive(gpu_ctx, oracle, seed, n):
     o = oracle.ransac(p1, p2, None, model=1, prob=0.99, threshold=3.0, fixed_count=nh,
                       want_counts=True)
     table, nmodels, counts, models = _dump(gpu_ctx, nh, 7)
-    assert (table == oracle.sample_table_f(p1, p2, nh)).all()
+    assert (table == oracle.sample_table_fixed(n, 7, nh, p1, p2)).all()
     assert (counts == o["counts"]).all()
     assert r["ok"] == 1 and (mask == o["mask"]).all() and r["n_inliers"] == o["n_inliers"]
     assert _model_close(F, o["model"])

@@ -102,6 +102,41 @@ def test_sample_table_distinct_and_stream(oracle):
     assert small.min() >= 0 and small.max() < 6
 
 
+def test_fixed_table_rows_are_independent_and_distinct(oracle):
+    a = oracle.sample_table_fixed(3000, 5, 64)
+    b = oracle.sample_table_fixed(3000, 5, 2048)
+    assert (a == b[:64]).all()                       # row r does not depend on the row count
+    assert all(len(set(r)) == 5 for r in b.tolist())
+    assert b.min() >= 0 and b.max() < 3000
+    hist = np.bincount(b.ravel(), minlength=3000)
+    assert hist.max() < 20                           # no gross bias
+    small = oracle.sample_table_fixed(6, 5, 200)
+    assert all(sorted(set(r)) == sorted(r) for r in small.tolist())
+
+
+def test_real_roots_against_constructed_polynomials(oracle):
+    rng = np.random.default_rng(0)
+    for trial in range(600):
+        deg = int(rng.integers(1, 11))
+        nreal = int(rng.integers(0, deg + 1))
+        roots = list(rng.normal(size=nreal) * rng.choice([0.1, 1, 10, 100]))
+        p = np.poly1d([1.0])
+        for x in roots:
+            p *= np.poly1d([1, -x])
+        while p.order < deg - 1:
+            a, b = rng.normal(size=2)
+            p *= np.poly1d([1, -2 * a, a * a + b * b + 0.01])
+        if p.order < deg:
+            x = rng.normal()
+            p *= np.poly1d([1, -x])
+            roots.append(x)
+        got = oracle.real_roots(p.coeffs[::-1] * rng.normal() * 10)
+        want = np.sort(roots)
+        assert len(got) == len(want), (trial, want, got)
+        if len(want):
+            assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
 def test_update_num_iters(oracle):
     assert oracle.update_num_iters(0.99, 1 - 0.91, 5, 1000) == 5
     assert oracle.update_num_iters(0.99, 0.5, 5, 1000) == 145
@@ -196,6 +231,8 @@ def test_ransac_fixed_count_is_replayable(oracle):
     # the adaptive loop is a prefix replay of the fixed-count scores
     p1, p2, _, _ = synth.two_view(800, 21, inlier_frac=0.8)
     ra = oracle.ransac(p1, p2, synth.REF_K, want_counts=True)
-    rf = oracle.ransac(p1, p2, synth.REF_K, fixed_count=ra["iters"], want_counts=True)
+    table = oracle.sample_table(800, 5, ra["iters"])     # the rows the adaptive loop drew
+    rf = oracle.ransac(p1, p2, synth.REF_K, fixed_count=ra["iters"], sample_table=table,
+                       want_counts=True)
     assert (ra["counts"][:ra["iters"]] == rf["counts"][:ra["iters"]]).all()
     assert (ra["mask"] == rf["mask"]).all()
