@@ -6,7 +6,7 @@ import torch
 from sfm_amd import matcher, synth
 
 def main():
-    sizes = [int(a) for a in sys.argv[1:]] or [8192, 20000, 32768]
+    sizes = [int(a) for a in sys.argv[1:]] or [8192, 32768]
     ctx = matcher.Context(0)
     ctx.profile_enable(True)
     for n in sizes:
@@ -14,7 +14,7 @@ def main():
         iq = matcher.Image(ctx, Q); it = matcher.Image(ctx, T)
         out = torch.empty(n * 2 * 16, dtype=torch.uint8, device="cuda")
         cnt = torch.empty(n, dtype=torch.int32, device="cuda")
-        for variant in (0, 1):
+        for variant in [int(v) for v in os.environ.get('VARIANTS','0,1,2,3').split(',')]:
             ctx._L.sfm_gpu_debug_set_knn_variant(ctx.handle, variant)
             for _ in range(3):
                 matcher.knn_match_images(ctx, iq, it, 2, (out.data_ptr(), cnt.data_ptr()))
@@ -26,6 +26,12 @@ def main():
             msf, _ = ctx.profile_query("knn_finalize")
             ops = 2.0 * n * n * 128
             t = ms / k * 1e-3
+            if variant >= 64:
+                st = np.zeros(3, np.uint32)
+                matcher.knn_match_images(ctx, iq, it, 2, (out.data_ptr(), cnt.data_ptr()))
+                ctx._L.sfm_gpu_debug_knn_stats(ctx.handle, n, st.ctypes.data)
+                print("   stats: checks=%d triggers=%d (%.1f%%) candidate lanes/trigger=%.2f" %
+                      (st[0], st[1], 100.0 * st[1] / max(st[0], 1), st[2] / max(st[1], 1)))
             print("n=%d variant=%d knn2_mfma %.1f us  %.1f TOP/s (%.1f%% of 5000)  finalize %.1f us" %
                   (n, variant, t * 1e6, ops / t / 1e12, ops / t / 5e15 * 100, msf / k * 1e3), flush=True)
         iq.close(); it.close()

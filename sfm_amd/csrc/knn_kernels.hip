@@ -19,6 +19,8 @@
 // packs key and row-in-chunk into one u32 and (min, med3) keep the two
 // smallest.  Ties on the key resolve to the lowest train row, as OpenCV's
 // ascending insertion scan does.
+#include <type_traits>
+
 #include "sfm_internal.h"
 
 namespace sfm {
@@ -92,54 +94,37 @@ __global__ void __launch_bounds__(256) prep_rows_kernel(const PrepJob* __restric
 }
 
 // ------------------------------------------------------------- knn2_mfma ----
-constexpr int ST = 128;  // train rows staged in LDS per step
-constexpr int LDS_DESC = ST * DIM;
-constexpr int LDS_BYTES = LDS_DESC + ST * 4 * 2;
+constexpr int ST = 128;                      // train rows staged in LDS per step
+constexpr int LDS_DESC = ST * DIM;           // descriptors of one stage
+constexpr int LDS_STAGE = LDS_DESC + ST * 8; // + cin[ST] + low[ST]
 
-// Update path for one 32x32 tile of one query block.  acc = x values of this
-// lane's query against its 16 train rows; low_tile points at low[] of the
-// tile's first row in LDS.
-__device__ __forceinline__ void topk_update(const v16i& acc, const unsigned char* low_tile, int h,
-                                            int32_t base, uint32_t& m1, uint32_t& m2, int32_t& g1,
-                                            int32_t& g2, uint32_t& thr)
+// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).
+// Keeps per-query-block state arrays indexed by constants only, so they stay
+// in registers.
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
 {
-    const uint32_t om1 = m1, om2 = m2;
-    uint32_t a = m1, b = m2;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const v4i lw = *(const v4i*)(low_tile + (8 * g + 4 * h) * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t p = ((uint32_t)acc[4 * g + i] << 9) + (uint32_t)lw[i];
-            const uint32_t nb = umed3(a, b, p);
-            a = umin32(a, p);
-            b = nb;
-        }
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
     }
-    // Recover which rows the survivors came from.  Entries carried over from
-    // earlier chunks have their index field cleared, so an equal key from the
-    // current chunk never displaces them (lowest train row wins ties).
-    const int32_t ia = base + (int32_t)(a & 255u);
-    const int32_t ib = base + (int32_t)(b & 255u);
-    const bool new1 = a != om1;
-    const int32_t ng2 = new1 ? (b == om1 ? g1 : ib) : (b != om2 ? ib : g2);
-    g1 = new1 ? ia : g1;
-    g2 = ng2;
-    m1 = a;
-    m2 = b;
-    thr = b >> 9;
+}
+
+// 16 bytes per lane from global memory straight into LDS at
+// lds_wave_base + 16 * lane (the LDS side of the instruction is not a scatter).
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 template <int QB, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
-knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int n_splits, int chunks_per_split)
+knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int n_splits, int chunks_per_split, int ablate)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    unsigned char* const lds_cin = lds + LDS_DESC;
-    unsigned char* const lds_low = lds_cin + ST * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * LDS_STAGE];
 
     const KnnJob job = jobs[blockIdx.z];
-    constexpr int NT = WAVES * 64;
     constexpr int QPB = WAVES * QB * 32;
     if ((int)blockIdx.x * QPB >= job.n_query) return;
     const int c0 = blockIdx.y * chunks_per_split;
@@ -160,99 +145,219 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int n_splits, int chunks_per_s
 #pragma unroll
         for (int s = 0; s < 4; ++s) bq[qb][s] = ~qp[s];
     }
-    uint32_t m1[QB], m2[QB], thr[QB];
-    int32_t g1[QB], g2[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
+    // per-query-block state as register vectors (constant indices only)
+    typedef uint32_t uQ __attribute__((ext_vector_type(QB)));
+    typedef int32_t iQ __attribute__((ext_vector_type(QB)));
+    uQ m1, m2, thr;
+    iQ g1, g2;
+    static_for<QB>([&](auto qbc) {
+        constexpr int qb = decltype(qbc)::value;
         m1[qb] = m2[qb] = 0xFFFFFFFFu;
         thr[qb] = 0x7FFFFFu;
         g1[qb] = g2[qb] = -1;
-    }
+    });
 
-    for (int c = c0; c < c1; ++c) {
-        for (int st = 0; st < CHUNK / ST; ++st) {
-            const int row0 = c * CHUNK + st * ST;
-            __syncthreads();
-            // Stage ST rows.  LDS image: row-major 128-B rows of eight 16-B
-            // slots, slot cs of row r holding source chunk cs ^ ((r >> 1) & 7),
-            // which makes the ds_read_b128 fragment reads below conflict-free.
-            for (int slot = threadIdx.x; slot < ST * 8; slot += NT) {
-                const int r = slot >> 3, cs = slot & 7, cc = cs ^ ((r >> 1) & 7);
-                const v4i v = *(const v4i*)(job.t_desc + (size_t)(row0 + r) * DIM + cc * 16);
-                *(v4i*)(lds + slot * 16) = v;
-            }
-            if (threadIdx.x < ST / 4) {
-                *(v4i*)(lds_cin + threadIdx.x * 16) = *(const v4i*)(job.t_cin + row0 + threadIdx.x * 4);
-            } else if (threadIdx.x < ST / 2) {
-                const int t = threadIdx.x - ST / 4;
-                *(v4i*)(lds_low + t * 16) = *(const v4i*)(job.t_low + row0 + t * 4);
-            }
-            __syncthreads();
-#pragma unroll 1
-            for (int tile = 0; tile < ST / 32; ++tile) {
-                const int r = tile * 32 + col;
-                const int swz = (r >> 1) & 7;
-                v4i a[4];
+    // Stage image in LDS: row-major 128-B rows of eight 16-B slots, slot cs of
+    // row r holding source chunk cs ^ ((r >> 1) & 7), which makes the
+    // ds_read_b128 fragment reads conflict-free; then cin[ST], low[ST].  The
+    // DMA writes LDS linearly, so the permutation is applied to the source
+    // address.  One wave-instruction moves 8 rows.
+    const int dma_r = lane >> 3;                 // row within the 8-row piece
+    const int dma_cs = lane & 7;
+    auto issue_stage = [&](int buf, int row0) {
+        unsigned char* dst = lds + buf * LDS_STAGE;
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    a[s] = *(const v4i*)(lds + (r * 8 + ((4 * h + s) ^ swz)) * 16);
-                // accumulator register 4g+i of this lane is train row 8g + 4h + i
-                v16i cinv;
+        for (int k = wave; k < ST / 8; k += WAVES) {
+            const int r = 8 * k + dma_r;
+            const int cc = dma_cs ^ ((r >> 1) & 7);
+            glds16(job.t_desc + (size_t)(row0 + r) * DIM + cc * 16, dst + k * 1024);
+        }
+        if (wave == WAVES - 1) {
+            const int32_t* src = lane < 32 ? job.t_cin + row0 + lane * 4 : job.t_low + row0 + (lane - 32) * 4;
+            glds16(src, dst + LDS_DESC);
+        }
+    };
+
+    // When the train sweep is split over several workgroups they tighten each
+    // other's thresholds through job.thr_glob[q], an upper bound of query q's
+    // final second-best x: a row above it cannot be in the top-2 whichever
+    // workgroup saw the rows that set it.  Values only ever decrease and a
+    // stale read is merely a looser bound, so no ordering is needed.
+    const bool coop = n_splits > 1;
+    uQ pend, pub;
+    static_for<QB>([&](auto qbc) {
+        constexpr int qb = decltype(qbc)::value;
+        pend[qb] = pub[qb] = 0x7FFFFFu;
+    });
+
+    unsigned dbg_checks = 0, dbg_trig = 0, dbg_lanes = 0;  // ablate >= 4: update-path statistics
+    struct Frag {
+        v4i a[4];
+        v4i c[4];
+    };
+    auto load_frag = [&](Frag& f, const unsigned char* buf, int tile) {
+        const int r = tile * 32 + col;
+        const int swz = (r >> 1) & 7;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f.a[k] = *(const v4i*)(buf + (r * 8 + ((4 * h + k) ^ swz)) * 16);
+        // accumulator register 4g+i of this lane is train row 8g + 4h + i
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            f.c[g] = *(const v4i*)(buf + LDS_DESC + (tile * 32 + 8 * g + 4 * h) * 4);
+    };
+    auto compute_tile = [&](const Frag& f, const unsigned char* low_tile, int32_t chunk_base) {
+        v16i cinv;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            cinv[4 * g + 0] = f.c[g][0];
+            cinv[4 * g + 1] = f.c[g][1];
+            cinv[4 * g + 2] = f.c[g][2];
+            cinv[4 * g + 3] = f.c[g][3];
+        }
+        static_for<QB>([&](auto qbc) {
+            constexpr int qb = decltype(qbc)::value;
+            v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[0], bq[qb][0], cinv, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[1], bq[qb][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[2], bq[qb][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[3], bq[qb][3], acc, 0, 0, 0);
+            if (ablate == 2) {  // timing experiment: MFMA only
+                asm volatile("" ::"v"(acc));
+                return;
+            }
+            uint32_t tg[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                tg[g] = umin32(umin32(umin32((uint32_t)acc[4 * g], (uint32_t)acc[4 * g + 1]),
+                                      (uint32_t)acc[4 * g + 2]), (uint32_t)acc[4 * g + 3]);
+            const uint32_t t = umin32(umin32(umin32(tg[0], tg[1]), tg[2]), tg[3]);
+            if (ablate == 1) {  // timing experiment: never update
+                asm volatile("" ::"v"(t));
+                return;
+            }
+            if (ablate >= 4) dbg_checks++;
+            if (ablate == 3 || __builtin_amdgcn_ballot_w64(t <= thr[qb]) != 0) {
+                if (ablate >= 4) {
+                    dbg_trig++;
+                    dbg_lanes += __popcll(__builtin_amdgcn_ballot_w64(t <= thr[qb]));
+                }
+                // Update path, one quartet of rows at a time, skipping quartets
+                // that hold no candidate for any lane.
+                const uint32_t om1 = m1[qb], om2 = m2[qb];
+                const int32_t og1 = g1[qb], og2 = g2[qb];
+                uint32_t ma = om1, mb = om2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const v4i t = *(const v4i*)(lds_cin + (tile * 32 + 8 * g + 4 * h) * 4);
-                    cinv[4 * g + 0] = t[0];
-                    cinv[4 * g + 1] = t[1];
-                    cinv[4 * g + 2] = t[2];
-                    cinv[4 * g + 3] = t[3];
-                }
+                    if (__builtin_amdgcn_ballot_w64(tg[g] <= thr[qb]) != 0) {
+                        const v4i lw = *(const v4i*)(low_tile + (8 * g + 4 * h) * 4);
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) {
-                    v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], bq[qb][0], cinv, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[1], bq[qb][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[2], bq[qb][2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[3], bq[qb][3], acc, 0, 0, 0);
-                    uint32_t t = umin32(umin32((uint32_t)acc[0], (uint32_t)acc[1]), (uint32_t)acc[2]);
-#pragma unroll
-                    for (int i = 3; i < 15; i += 2)
-                        t = umin32(umin32(t, (uint32_t)acc[i]), (uint32_t)acc[i + 1]);
-                    t = umin32(t, (uint32_t)acc[15]);
-                    if (__builtin_amdgcn_ballot_w64(t <= thr[qb]) != 0) {
-                        topk_update(acc, lds_low + tile * 32 * 4, h, c * CHUNK, m1[qb], m2[qb],
-                                    g1[qb], g2[qb], thr[qb]);
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t p = ((uint32_t)acc[4 * g + i] << 9) + (uint32_t)lw[i];
+                            const uint32_t nb = umed3(ma, mb, p);
+                            ma = umin32(ma, p);
+                            mb = nb;
+                        }
                     }
                 }
+                // Recover which rows the survivors came from.  Entries carried over
+                // from earlier chunks have their index field cleared, so an equal key
+                // from the current chunk never displaces them (lowest train row wins
+                // ties).
+                const int32_t ia = chunk_base + (int32_t)(ma & 255u);
+                const int32_t ib = chunk_base + (int32_t)(mb & 255u);
+                const bool new1 = ma != om1;
+                const int32_t ng2_if_new1 = (mb == om1) ? og1 : ib;
+                const int32_t ng2_if_old1 = (mb != om2) ? ib : og2;
+                g1[qb] = new1 ? ia : og1;
+                g2[qb] = new1 ? ng2_if_new1 : ng2_if_old1;
+                m1[qb] = ma;
+                m2[qb] = mb;
+                // Lanes l and l+32 serve the same query: a row that cannot beat the
+                // better of their two second-best keys cannot be in the query's top-2.
+                const uint32_t mo = (uint32_t)__shfl_xor((int)mb, 32);
+                thr[qb] = umin32(thr[qb], umin32(mb, mo) >> 9);
             }
+        });
+    };
+
+    const int n_stage = (c1 - c0) * (CHUNK / ST);
+    if (n_stage > 0) issue_stage(0, c0 * CHUNK);
+    for (int s = 0; s < n_stage; ++s) {
+        // Hand-placed wait + raw barrier (the compiler does not order LDS-DMA by
+        // itself): this wave's DMA of stage s and its threshold loads have
+        // landed (vmcnt), then everyone's have (barrier), and every wave is done
+        // reading the buffer that stage s+1 is about to overwrite.  The
+        // threshold merge sits between the two so that no wait for it can end
+        // up behind the next DMA issue, where it would wait for that DMA too.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_for<QB>([&](auto qbc) {
+            constexpr int qb = decltype(qbc)::value;
+            uint32_t v = umin32(thr[qb], pend[qb]);
+            asm volatile("" : "+v"(v));  // pins the merge (and its operand wait) here
+            thr[qb] = v;
+        });
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < n_stage) issue_stage((s + 1) & 1, c0 * CHUNK + (s + 1) * ST);
+        if (coop) {
+            static_for<QB>([&](auto qbc) {
+                constexpr int qb = decltype(qbc)::value;
+                typedef __attribute__((address_space(1))) uint32_t gu32;
+                gu32* gp = (gu32*)(job.thr_glob + q_base + qb * 32 + col);
+                if (thr[qb] < pub[qb]) {
+                    __hip_atomic_fetch_min(gp, thr[qb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pub[qb] = thr[qb];
+                }
+                pend[qb] = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
         }
-        // entries now belong to an earlier chunk: clear their row-in-chunk
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            m1[qb] &= ~0xFFu;
-            m2[qb] &= ~0xFFu;
+        const unsigned char* buf = lds + (s & 1) * LDS_STAGE;
+        const int32_t chunk_base = (c0 + s / (CHUNK / ST)) * CHUNK;
+        const unsigned char* buf_low = buf + LDS_DESC + ST * 4;
+        Frag f0, f1;
+        load_frag(f0, buf, 0);
+        load_frag(f1, buf, 1);
+        compute_tile(f0, buf_low, chunk_base);
+        load_frag(f0, buf, 2);
+        compute_tile(f1, buf_low + 32 * 4, chunk_base);
+        load_frag(f1, buf, 3);
+        compute_tile(f0, buf_low + 64 * 4, chunk_base);
+        compute_tile(f1, buf_low + 96 * 4, chunk_base);
+        if ((s + 1) % (CHUNK / ST) == 0) {
+            // entries now belong to an earlier chunk: clear their row-in-chunk
+            static_for<QB>([&](auto qbc) {
+                constexpr int qb = decltype(qbc)::value;
+                m1[qb] &= ~0xFFu;
+                m2[qb] &= ~0xFFu;
+            });
         }
     }
 
+    if (ablate >= 4 && lane == 0) {
+        atomicAdd(job.thr_glob + job.q_rows_alloc + 0, dbg_checks);
+        atomicAdd(job.thr_glob + job.q_rows_alloc + 1, dbg_trig);
+        atomicAdd(job.thr_glob + job.q_rows_alloc + 2, dbg_lanes);
+    }
     // Lanes l and l+32 hold the same query over disjoint rows: merge, then
     // lane l < 32 writes the split's partial result.
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
+    static_for<QB>([&](auto qbc) {
+        constexpr int qb = decltype(qbc)::value;
         const unsigned long long a1 = ((unsigned long long)(m1[qb] >> 8) << 32) | (uint32_t)g1[qb];
         const unsigned long long a2 = ((unsigned long long)(m2[qb] >> 8) << 32) | (uint32_t)g2[qb];
         const unsigned long long b1 = __shfl_xor(a1, 32);
         const unsigned long long b2 = __shfl_xor(a2, 32);
         const bool afirst = a1 < b1;
         const unsigned long long f = afirst ? a1 : b1;
-        const unsigned long long s = afirst ? (b1 < a2 ? b1 : a2) : (a1 < b2 ? a1 : b2);
+        const unsigned long long s2 = afirst ? (b1 < a2 ? b1 : a2) : (a1 < b2 ? a1 : b2);
         if (h == 0) {
             const int q = q_base + qb * 32 + col;
             uint4 o;
             o.x = (uint32_t)(f >> 32);
             o.y = (uint32_t)f;
-            o.z = (uint32_t)(s >> 32);
-            o.w = (uint32_t)s;
+            o.z = (uint32_t)(s2 >> 32);
+            o.w = (uint32_t)s2;
             job.partial[(size_t)blockIdx.y * job.q_rows_alloc + q] = o;
         }
-    }
+    });
 }
 
 // ---------------------------------------------------------- finalisation ----
@@ -423,20 +528,24 @@ hipError_t launch_prep_rows(hipStream_t s, const PrepJob* jobs_dev, int n_jobs, 
     return hipGetLastError();
 }
 
-// variant: 0 = 4 waves x 4 query blocks (512 queries per workgroup)
-//          1 = 4 waves x 2 query blocks (256 queries per workgroup)
-static const int kVariantQPB[2] = {512, 256};
+// Workgroup shapes of the distance kernel: {query blocks per wave, waves}.
+//   0: 4 x 4 (512 queries / workgroup)   1: 2 x 4 (256)
+//   2: 2 x 8 (512)                       3: 4 x 8 (1024)
+static const int kVariantQPB[4] = {512, 256, 512, 1024};
 
 KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant)
 {
     KnnPlan p;
-    p.variant = force_variant >= 0 ? force_variant : 0;
+    p.ablate = force_variant >= 0 ? force_variant / 16 : 0;
+    if (force_variant >= 0) force_variant %= 16;
+    p.variant = (force_variant >= 0 && force_variant < 4) ? force_variant : 0;
     p.q_per_block = kVariantQPB[p.variant];
     const int t_chunks = (n_train_max + CHUNK - 1) / CHUNK;
     const long long qblocks = (long long)((n_query_max + p.q_per_block - 1) / p.q_per_block) * n_jobs;
-    // fill 256 CUs at least twice over before splitting no further
+    // The train sweep is split only as far as needed to give every CU work:
+    // short sweeps start with cold top-2 thresholds and update far more often.
     int splits = 1;
-    while (qblocks * splits < 512 && splits * 2 <= t_chunks && t_chunks / (splits * 2) >= 4)
+    while (qblocks * splits < 256 && splits * 2 <= t_chunks && t_chunks / (splits * 2) >= 4)
         splits *= 2;
     p.n_splits = splits;
     p.chunks_per_split = (t_chunks + splits - 1) / splits;
@@ -450,12 +559,24 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
 {
     const int qblocks = (q_rows_alloc_max + plan.q_per_block - 1) / plan.q_per_block;
     const dim3 grid(qblocks, plan.n_splits, n_jobs);
-    if (plan.variant == 0)
-        hipLaunchKernelGGL((knn2_mfma_kernel<4, 4>), grid, dim3(256), 0, s, jobs_dev, plan.n_splits,
-                           plan.chunks_per_split);
-    else
-        hipLaunchKernelGGL((knn2_mfma_kernel<2, 4>), grid, dim3(256), 0, s, jobs_dev, plan.n_splits,
-                           plan.chunks_per_split);
+    switch (plan.variant) {
+        case 1:
+            hipLaunchKernelGGL((knn2_mfma_kernel<2, 4>), grid, dim3(256), 0, s, jobs_dev, plan.n_splits,
+                               plan.chunks_per_split, plan.ablate);
+            break;
+        case 2:
+            hipLaunchKernelGGL((knn2_mfma_kernel<2, 8>), grid, dim3(512), 0, s, jobs_dev, plan.n_splits,
+                               plan.chunks_per_split, plan.ablate);
+            break;
+        case 3:
+            hipLaunchKernelGGL((knn2_mfma_kernel<4, 8>), grid, dim3(512), 0, s, jobs_dev, plan.n_splits,
+                               plan.chunks_per_split, plan.ablate);
+            break;
+        default:
+            hipLaunchKernelGGL((knn2_mfma_kernel<4, 4>), grid, dim3(256), 0, s, jobs_dev, plan.n_splits,
+                               plan.chunks_per_split, plan.ablate);
+            break;
+    }
     return hipGetLastError();
 }
 

@@ -101,7 +101,7 @@ struct sfm_gpu_ctx {
 
     sfm::DevBuf raw_q, raw_t;
     sfm::ImageStore tmp_q, tmp_t;
-    sfm::DevBuf partial, out, counts, redo, jobs, flags, prepjobs;
+    sfm::DevBuf partial, out, counts, redo, jobs, flags, prepjobs, thrglob;
     // ransac workspaces
     sfm::DevBuf rs_pts, rs_table, rs_models, rs_counts, rs_mask, rs_misc;
     // match_pairs workspaces

@@ -97,6 +97,12 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
     job.out = out_dev;
     job.counts = cnt_dev;
     job.redo = ctx->redo.as<int32_t>();
+    SFM_HIP(ctx, ctx->thrglob.reserve((size_t)q.rows_alloc * 4 + 16));
+    job.thr_glob = ctx->thrglob.as<uint32_t>();
+    if (plan.n_splits > 1)
+        SFM_HIP(ctx, hipMemsetAsync(ctx->thrglob.p, 0x7F, (size_t)q.rows_alloc * 4, ctx->stream));
+    if (plan.ablate >= 4)  // statistics words behind the thresholds
+        SFM_HIP(ctx, hipMemsetAsync(ctx->thrglob.as<char>() + (size_t)q.rows_alloc * 4, 0, 16, ctx->stream));
     job.n_query = nq;
     job.n_train = nt;
     job.q_rows_alloc = q.rows_alloc;
@@ -169,7 +175,7 @@ void sfm_gpu_destroy(sfm_gpu_ctx* c)
             (void)hipEventDestroy(pr.second);
         }
     DevBuf* bufs[] = {&c->raw_q, &c->raw_t, &c->partial, &c->out, &c->counts, &c->redo, &c->jobs,
-                      &c->flags, &c->rs_pts, &c->rs_table, &c->rs_models, &c->rs_counts, &c->rs_mask,
+                      &c->flags, &c->prepjobs, &c->thrglob, &c->rs_pts, &c->rs_table, &c->rs_models, &c->rs_counts, &c->rs_mask,
                       &c->rs_misc, &c->mp_good, &c->mp_pts, &c->mp_ngood};
     for (DevBuf* b : bufs) b->release();
     c->tmp_q.release();
@@ -431,6 +437,18 @@ int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* c, int variant)
 {
     if (!c) return SFM_GPU_ERR_ARG;
     c->knn_variant = variant;
+    return SFM_GPU_OK;
+}
+
+// Update-path statistics of the last sfm_gpu_knn_match_images call made with
+// variant >= 64 (ablate 4): {tile checks, update passes, candidate lanes}.
+int sfm_gpu_debug_knn_stats(sfm_gpu_ctx* ctx, int q_rows, uint32_t* out3)
+{
+    if (!ctx || !out3 || !ctx->thrglob.p) return SFM_GPU_ERR_ARG;
+    const int rows = image_rows_alloc(q_rows);
+    SFM_HIP(ctx, hipMemcpyAsync(out3, ctx->thrglob.as<char>() + (size_t)rows * 4, 12, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SFM_GPU_OK;
 }
 

@@ -64,6 +64,7 @@ struct KnnJob {
     sfm_gpu_dmatch* out;  // [n_query][k]
     int32_t* counts;      // [n_query]
     int32_t* redo;        // [0] = count, [1..] = query rows needing the float-ranked pass
+    uint32_t* thr_glob;   // [q_rows_alloc] shared second-best bounds (split sweeps), preset to >= 0x7FFFFF
     int n_query;
     int n_train;
     int q_rows_alloc;
@@ -94,6 +95,7 @@ struct KnnPlan {
     int chunks_per_split;
     int q_per_block;
     int variant;
+    int ablate;  // timing experiments only: 1 = never update, 2 = MFMA only (wrong results)
 };
 KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant);
 hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_rows_alloc_max,

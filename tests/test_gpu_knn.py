@@ -33,7 +33,7 @@ def test_mfma_operand_and_accumulator_layout(gpu_ctx):
     assert (c == ref).all()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("nq,nt", [(1, 1), (5, 2), (33, 257), (257, 1000), (700, 3000)])
 def test_knn_small_shapes(gpu_ctx, oracle, variant, nq, nt):
     gpu_ctx._L.sfm_gpu_debug_set_knn_variant(gpu_ctx.handle, variant)
