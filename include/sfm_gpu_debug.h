@@ -15,10 +15,6 @@ extern "C" {
 /* Forces the workgroup shape of the distance kernel (-1: planner decides). */
 int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* ctx, int variant);
 
-/* Update-path statistics of the last sfm_gpu_knn_match_images call made with
- * variant + 64: {tile checks, update passes, candidate lanes} summed over waves. */
-int sfm_gpu_debug_knn_stats(sfm_gpu_ctx* ctx, int q_rows, uint32_t* out3);
-
 /* c[32][32] (int32) = a[32][32] * b^T with b given as [32 columns][32 k], all
  * host pointers, through one v_mfma_i32_32x32x32_i8 loaded the way the
  * distance kernel loads its operands. */

@@ -26,12 +26,6 @@ def main():
             msf, _ = ctx.profile_query("knn_finalize")
             ops = 2.0 * n * n * 128
             t = ms / k * 1e-3
-            if variant >= 64:
-                st = np.zeros(3, np.uint32)
-                matcher.knn_match_images(ctx, iq, it, 2, (out.data_ptr(), cnt.data_ptr()))
-                ctx._L.sfm_gpu_debug_knn_stats(ctx.handle, n, st.ctypes.data)
-                print("   stats: checks=%d triggers=%d (%.1f%%) candidate lanes/trigger=%.2f" %
-                      (st[0], st[1], 100.0 * st[1] / max(st[0], 1), st[2] / max(st[1], 1)))
             print("n=%d variant=%d knn2_mfma %.1f us  %.1f TOP/s (%.1f%% of 5000)  finalize %.1f us" %
                   (n, variant, t * 1e6, ops / t / 1e12, ops / t / 5e15 * 100, msf / k * 1e3), flush=True)
         iq.close(); it.close()

@@ -11,14 +11,13 @@
 //     Qn = sum (q-128)^2,   Tn = sum (t-127)^2 - 128.
 // For one query the ranking key is Tn + 2*dot.  The accumulator is preloaded
 // with cin[t] = floor(Tn/2) + KEY_OFFSET, so the MFMA chain leaves
-// x = dot + cin in registers and key = 2x + (Tn & 1) (+ a constant).  Rows with
-// x above the lane's current second-best x cannot enter the top-2, which a
-// min3 tree over the 16 accumulators and one wave-wide branch decide; only
-// tiles that pass take the update path, where
-//     p = (x << 9) + low[t],  low[t] = (Tn & 1) << 8 | (t & 255)
-// packs key and row-in-chunk into one u32 and (min, med3) keep the two
-// smallest.  Ties on the key resolve to the lowest train row, as OpenCV's
-// ascending insertion scan does.
+// x = dot + cin = floor(key/2) + const in registers, already comparable across
+// train rows.  The sweep keeps, per query, the groups of 16 rows with the
+// smallest minimum x; a second kernel computes exact integer distances for the
+// rows of the two best groups and ranks them by (d2, row), which is OpenCV's
+// (float distance, ascending train index) order whenever d2 < 2^22.  The rare
+// queries where that shortcut is not provably exact go through an exhaustive
+// float-ranked pass.
 #include <type_traits>
 
 #include "sfm_internal.h"
@@ -83,12 +82,10 @@ __global__ void __launch_bounds__(256) prep_rows_kernel(const PrepJob* __restric
             const int tn = n2 + 2 * s;  // = sum (v-127)^2 - 128, in [-128, 2097024]
             img.qn[row] = n2;
             img.cin[row] = (tn >> 1) + KEY_OFFSET;  // arithmetic shift = floor
-            img.low[row] = ((tn & 1) << 8) | (row & 255);
             if (job.kp_src && img.kp) img.kp[row] = job.kp_src[row];
         } else {
             img.qn[row] = 0;
             img.cin[row] = PAD_CIN;
-            img.low[row] = row & 255;
         }
     }
 }
@@ -96,11 +93,10 @@ __global__ void __launch_bounds__(256) prep_rows_kernel(const PrepJob* __restric
 // ------------------------------------------------------------- knn2_mfma ----
 constexpr int ST = 128;                      // train rows staged in LDS per step
 constexpr int LDS_DESC = ST * DIM;           // descriptors of one stage
-constexpr int LDS_STAGE = LDS_DESC + ST * 8; // + cin[ST] + low[ST]
+constexpr int LDS_STAGE = LDS_DESC + ST * 4; // + cin[ST]
+constexpr int TILE_BITS = 9;                 // a sweep holds at most 512 tiles of 32 rows
 
 // Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).
-// Keeps per-query-block state arrays indexed by constants only, so they stay
-// in registers.
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f)
 {
@@ -118,9 +114,19 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Distance sweep.  Workgroup = WAVES waves, each owning QB blocks of 32
+// queries; blockIdx.y selects a contiguous part of the train rows (a sweep of
+// at most 512 tiles), blockIdx.z the job.
+//
+// Per 32x32 tile the accumulators of one lane are x for ONE query against 16
+// train rows (a "group": rows 8g+4h+i of the tile, g,i = 0..3).  The lane keeps
+// the three smallest group minima seen so far, the best two tagged with their
+// tile: 8 min3 + 1 pack + 5 min/max/med3 per tile, no branch, no cross-lane
+// traffic.  The exact neighbours are then picked by knn_rescan_kernel among
+// the rows of the two best groups of each query.
 template <int QB, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
-knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int n_splits, int chunks_per_split, int ablate)
+knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int ablate)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * LDS_STAGE];
 
@@ -147,22 +153,18 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int n_splits, int chunks_per_s
     }
     // per-query-block state as register vectors (constant indices only)
     typedef uint32_t uQ __attribute__((ext_vector_type(QB)));
-    typedef int32_t iQ __attribute__((ext_vector_type(QB)));
-    uQ m1, m2, thr;
-    iQ g1, g2;
+    uQ m1, m2, m3;
     static_for<QB>([&](auto qbc) {
         constexpr int qb = decltype(qbc)::value;
-        m1[qb] = m2[qb] = 0xFFFFFFFFu;
-        thr[qb] = 0x7FFFFFu;
-        g1[qb] = g2[qb] = -1;
+        m1[qb] = m2[qb] = m3[qb] = 0xFFFFFFFFu;
     });
 
     // Stage image in LDS: row-major 128-B rows of eight 16-B slots, slot cs of
     // row r holding source chunk cs ^ ((r >> 1) & 7), which makes the
-    // ds_read_b128 fragment reads conflict-free; then cin[ST], low[ST].  The
-    // DMA writes LDS linearly, so the permutation is applied to the source
-    // address.  One wave-instruction moves 8 rows.
-    const int dma_r = lane >> 3;                 // row within the 8-row piece
+    // ds_read_b128 fragment reads conflict-free; then cin[ST].  The DMA writes
+    // LDS linearly, so the permutation is applied to the source address.  One
+    // wave-instruction moves 8 rows.
+    const int dma_r = lane >> 3;
     const int dma_cs = lane & 7;
     auto issue_stage = [&](int buf, int row0) {
         unsigned char* dst = lds + buf * LDS_STAGE;
@@ -172,25 +174,9 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int n_splits, int chunks_per_s
             const int cc = dma_cs ^ ((r >> 1) & 7);
             glds16(job.t_desc + (size_t)(row0 + r) * DIM + cc * 16, dst + k * 1024);
         }
-        if (wave == WAVES - 1) {
-            const int32_t* src = lane < 32 ? job.t_cin + row0 + lane * 4 : job.t_low + row0 + (lane - 32) * 4;
-            glds16(src, dst + LDS_DESC);
-        }
+        if (wave == WAVES - 1 && lane < ST / 4) glds16(job.t_cin + row0 + lane * 4, dst + LDS_DESC);
     };
 
-    // When the train sweep is split over several workgroups they tighten each
-    // other's thresholds through job.thr_glob[q], an upper bound of query q's
-    // final second-best x: a row above it cannot be in the top-2 whichever
-    // workgroup saw the rows that set it.  Values only ever decrease and a
-    // stale read is merely a looser bound, so no ordering is needed.
-    const bool coop = n_splits > 1;
-    uQ pend, pub;
-    static_for<QB>([&](auto qbc) {
-        constexpr int qb = decltype(qbc)::value;
-        pend[qb] = pub[qb] = 0x7FFFFFu;
-    });
-
-    unsigned dbg_checks = 0, dbg_trig = 0, dbg_lanes = 0;  // ablate >= 4: update-path statistics
     struct Frag {
         v4i a[4];
         v4i c[4];
@@ -205,7 +191,7 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int n_splits, int chunks_per_s
         for (int g = 0; g < 4; ++g)
             f.c[g] = *(const v4i*)(buf + LDS_DESC + (tile * 32 + 8 * g + 4 * h) * 4);
     };
-    auto compute_tile = [&](const Frag& f, const unsigned char* low_tile, int32_t chunk_base) {
+    auto compute_tile = [&](const Frag& f, uint32_t tile_id) {
         v16i cinv;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -220,62 +206,21 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int n_splits, int chunks_per_s
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[1], bq[qb][1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[2], bq[qb][2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[3], bq[qb][3], acc, 0, 0, 0);
-            if (ablate == 2) {  // timing experiment: MFMA only
+            if (ablate == 2) {  // timing experiment: MFMA only (wrong results)
                 asm volatile("" ::"v"(acc));
                 return;
             }
-            uint32_t tg[4];
+            uint32_t t = umin32(umin32((uint32_t)acc[0], (uint32_t)acc[1]), (uint32_t)acc[2]);
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                tg[g] = umin32(umin32(umin32((uint32_t)acc[4 * g], (uint32_t)acc[4 * g + 1]),
-                                      (uint32_t)acc[4 * g + 2]), (uint32_t)acc[4 * g + 3]);
-            const uint32_t t = umin32(umin32(umin32(tg[0], tg[1]), tg[2]), tg[3]);
-            if (ablate == 1) {  // timing experiment: never update
-                asm volatile("" ::"v"(t));
-                return;
-            }
-            if (ablate >= 4) dbg_checks++;
-            if (ablate == 3 || __builtin_amdgcn_ballot_w64(t <= thr[qb]) != 0) {
-                if (ablate >= 4) {
-                    dbg_trig++;
-                    dbg_lanes += __popcll(__builtin_amdgcn_ballot_w64(t <= thr[qb]));
-                }
-                // Update path, one quartet of rows at a time, skipping quartets
-                // that hold no candidate for any lane.
-                const uint32_t om1 = m1[qb], om2 = m2[qb];
-                const int32_t og1 = g1[qb], og2 = g2[qb];
-                uint32_t ma = om1, mb = om2;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (__builtin_amdgcn_ballot_w64(tg[g] <= thr[qb]) != 0) {
-                        const v4i lw = *(const v4i*)(low_tile + (8 * g + 4 * h) * 4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const uint32_t p = ((uint32_t)acc[4 * g + i] << 9) + (uint32_t)lw[i];
-                            const uint32_t nb = umed3(ma, mb, p);
-                            ma = umin32(ma, p);
-                            mb = nb;
-                        }
-                    }
-                }
-                // Recover which rows the survivors came from.  Entries carried over
-                // from earlier chunks have their index field cleared, so an equal key
-                // from the current chunk never displaces them (lowest train row wins
-                // ties).
-                const int32_t ia = chunk_base + (int32_t)(ma & 255u);
-                const int32_t ib = chunk_base + (int32_t)(mb & 255u);
-                const bool new1 = ma != om1;
-                const int32_t ng2_if_new1 = (mb == om1) ? og1 : ib;
-                const int32_t ng2_if_old1 = (mb != om2) ? ib : og2;
-                g1[qb] = new1 ? ia : og1;
-                g2[qb] = new1 ? ng2_if_new1 : ng2_if_old1;
-                m1[qb] = ma;
-                m2[qb] = mb;
-                // Lanes l and l+32 serve the same query: a row that cannot beat the
-                // better of their two second-best keys cannot be in the query's top-2.
-                const uint32_t mo = (uint32_t)__shfl_xor((int)mb, 32);
-                thr[qb] = umin32(thr[qb], umin32(mb, mo) >> 9);
-            }
+            for (int i = 3; i < 15; i += 2)
+                t = umin32(umin32(t, (uint32_t)acc[i]), (uint32_t)acc[i + 1]);
+            t = umin32(t, (uint32_t)acc[15]);
+            const uint32_t p = (t << TILE_BITS) | tile_id;
+            const uint32_t n3 = umin32(m3[qb], umax32(m2[qb], p));
+            const uint32_t n2 = umed3(m1[qb], m2[qb], p);
+            m1[qb] = umin32(m1[qb], p);
+            m2[qb] = n2;
+            m3[qb] = n3;
         });
     };
 
@@ -283,84 +228,41 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int n_splits, int chunks_per_s
     if (n_stage > 0) issue_stage(0, c0 * CHUNK);
     for (int s = 0; s < n_stage; ++s) {
         // Hand-placed wait + raw barrier (the compiler does not order LDS-DMA by
-        // itself): this wave's DMA of stage s and its threshold loads have
-        // landed (vmcnt), then everyone's have (barrier), and every wave is done
-        // reading the buffer that stage s+1 is about to overwrite.  The
-        // threshold merge sits between the two so that no wait for it can end
-        // up behind the next DMA issue, where it would wait for that DMA too.
+        // itself): this wave's DMA of stage s has landed (vmcnt), then everyone's
+        // has (barrier), and every wave is done reading the buffer that stage
+        // s+1 is about to overwrite.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        static_for<QB>([&](auto qbc) {
-            constexpr int qb = decltype(qbc)::value;
-            uint32_t v = umin32(thr[qb], pend[qb]);
-            asm volatile("" : "+v"(v));  // pins the merge (and its operand wait) here
-            thr[qb] = v;
-        });
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < n_stage) issue_stage((s + 1) & 1, c0 * CHUNK + (s + 1) * ST);
-        if (coop) {
-            static_for<QB>([&](auto qbc) {
-                constexpr int qb = decltype(qbc)::value;
-                typedef __attribute__((address_space(1))) uint32_t gu32;
-                gu32* gp = (gu32*)(job.thr_glob + q_base + qb * 32 + col);
-                if (thr[qb] < pub[qb]) {
-                    __hip_atomic_fetch_min(gp, thr[qb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    pub[qb] = thr[qb];
-                }
-                pend[qb] = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            });
-        }
         const unsigned char* buf = lds + (s & 1) * LDS_STAGE;
-        const int32_t chunk_base = (c0 + s / (CHUNK / ST)) * CHUNK;
-        const unsigned char* buf_low = buf + LDS_DESC + ST * 4;
+        const uint32_t tile0 = (uint32_t)s * (ST / 32);
         Frag f0, f1;
         load_frag(f0, buf, 0);
         load_frag(f1, buf, 1);
-        compute_tile(f0, buf_low, chunk_base);
+        compute_tile(f0, tile0 + 0);
         load_frag(f0, buf, 2);
-        compute_tile(f1, buf_low + 32 * 4, chunk_base);
+        compute_tile(f1, tile0 + 1);
         load_frag(f1, buf, 3);
-        compute_tile(f0, buf_low + 64 * 4, chunk_base);
-        compute_tile(f1, buf_low + 96 * 4, chunk_base);
-        if ((s + 1) % (CHUNK / ST) == 0) {
-            // entries now belong to an earlier chunk: clear their row-in-chunk
-            static_for<QB>([&](auto qbc) {
-                constexpr int qb = decltype(qbc)::value;
-                m1[qb] &= ~0xFFu;
-                m2[qb] &= ~0xFFu;
-            });
-        }
+        compute_tile(f0, tile0 + 2);
+        compute_tile(f1, tile0 + 3);
     }
 
-    if (ablate >= 4 && lane == 0) {
-        atomicAdd(job.thr_glob + job.q_rows_alloc + 0, dbg_checks);
-        atomicAdd(job.thr_glob + job.q_rows_alloc + 1, dbg_trig);
-        atomicAdd(job.thr_glob + job.q_rows_alloc + 2, dbg_lanes);
-    }
-    // Lanes l and l+32 hold the same query over disjoint rows: merge, then
-    // lane l < 32 writes the split's partial result.
+    // one record per (split, query, lane half): best two groups, third minimum,
+    // global index of the sweep's first tile
     static_for<QB>([&](auto qbc) {
         constexpr int qb = decltype(qbc)::value;
-        const unsigned long long a1 = ((unsigned long long)(m1[qb] >> 8) << 32) | (uint32_t)g1[qb];
-        const unsigned long long a2 = ((unsigned long long)(m2[qb] >> 8) << 32) | (uint32_t)g2[qb];
-        const unsigned long long b1 = __shfl_xor(a1, 32);
-        const unsigned long long b2 = __shfl_xor(a2, 32);
-        const bool afirst = a1 < b1;
-        const unsigned long long f = afirst ? a1 : b1;
-        const unsigned long long s2 = afirst ? (b1 < a2 ? b1 : a2) : (a1 < b2 ? a1 : b2);
-        if (h == 0) {
-            const int q = q_base + qb * 32 + col;
-            uint4 o;
-            o.x = (uint32_t)(f >> 32);
-            o.y = (uint32_t)f;
-            o.z = (uint32_t)(s2 >> 32);
-            o.w = (uint32_t)s2;
-            job.partial[(size_t)blockIdx.y * job.q_rows_alloc + q] = o;
-        }
+        const int q = q_base + qb * 32 + col;
+        uint4 o;
+        o.x = m1[qb];
+        o.y = m2[qb];
+        o.z = m3[qb];
+        o.w = (uint32_t)(c0 * (CHUNK / 32));
+        job.partial[((size_t)blockIdx.y * job.q_rows_alloc + q) * 2 + h] = o;
     });
 }
 
-// ---------------------------------------------------------- finalisation ----
+// ---------------------------------------------------------------- rescan ----
 
 // sqrtf of an integer < 2^24, correctly rounded, independent of the accuracy of
 // the device's double sqrt: the candidate is checked against the two
@@ -379,40 +281,97 @@ __device__ __forceinline__ float sqrt_exact_u32(uint32_t n)
     return f;
 }
 
+typedef unsigned long long u64;
+
+// keeps the three smallest of (a1<=a2<=a3) and v
+__device__ __forceinline__ void insert3(u64& a1, u64& a2, u64& a3, u64 v)
+{
+    if (v < a3) {
+        a3 = v;
+        if (a3 < a2) { const u64 t = a2; a2 = a3; a3 = t; }
+        if (a2 < a1) { const u64 t = a1; a1 = a2; a2 = t; }
+    }
+}
+
+// Exact neighbours from the sweep records.  32 lanes per query:
+//  1. the query's records (2 lane halves x n_splits) are reduced to the two
+//     best groups by (minimum x, tile, half) and to the smallest x of all the
+//     other groups;
+//  2. lane l computes the exact squared distance to row l%16 of group l/16;
+//  3. the two smallest (d2, row) are the neighbours.  Every row outside the two
+//     groups has x >= the third minimum, hence d2-key >= 2*third; if that does
+//     not exceed the key of the second neighbour found (a tie between group
+//     minima), or if d2 >= 2^22 where different d2 share one float sqrt, the
+//     query is queued for the exhaustive float-ranked pass instead.
 __global__ void __launch_bounds__(256)
-knn_finalize_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k)
+knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k)
 {
     const KnnJob job = jobs[blockIdx.y];
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= job.n_query) return;
-    unsigned long long f = ~0ull, s = ~0ull;
-    for (int sp = 0; sp < n_splits; ++sp) {
-        const uint4 p = job.partial[(size_t)sp * job.q_rows_alloc + q];
-        const unsigned long long b1 = ((unsigned long long)p.x << 32) | p.y;
-        const unsigned long long b2 = ((unsigned long long)p.z << 32) | p.w;
-        const bool afirst = f < b1;
-        const unsigned long long nf = afirst ? f : b1;
-        const unsigned long long ns = afirst ? (b1 < s ? b1 : s) : (f < b2 ? f : b2);
-        f = nf;
-        s = ns;
+    const int q = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int l = threadIdx.x & 31;
+    if (q >= job.n_query) return;  // whole 32-lane group leaves together
+    const u64 NONE = ~0ull;
+    u64 c1 = NONE, c2 = NONE, c3 = NONE;
+    for (int j = l; j < 2 * n_splits; j += 32) {
+        const int sp = j >> 1, hh = j & 1;
+        const uint4 r = job.partial[((size_t)sp * job.q_rows_alloc + q) * 2 + hh];
+        const uint32_t tmask = (1u << TILE_BITS) - 1u;
+        if (r.x != 0xFFFFFFFFu)
+            insert3(c1, c2, c3, ((u64)(r.x >> TILE_BITS) << 32) | (((r.w + (r.x & tmask)) << 1) | hh));
+        if (r.y != 0xFFFFFFFFu)
+            insert3(c1, c2, c3, ((u64)(r.y >> TILE_BITS) << 32) | (((r.w + (r.y & tmask)) << 1) | hh));
+        if (r.z != 0xFFFFFFFFu) insert3(c1, c2, c3, ((u64)(r.z >> TILE_BITS) << 32) | 0xFFFFFFFFu);
     }
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const u64 b1 = __shfl_xor(c1, off), b2 = __shfl_xor(c2, off), b3 = __shfl_xor(c3, off);
+        insert3(c1, c2, c3, b1);
+        insert3(c1, c2, c3, b2);
+        insert3(c1, c2, c3, b3);
+    }
+    // every lane now holds the same c1 <= c2 <= c3
+    const u64 grp = (l < 16) ? c1 : c2;
+    const uint32_t third_x = (uint32_t)(c3 >> 32);  // 0xFFFFFFFF when there is no third group
+    u64 e = NONE;
     const int qn = job.q_qn[q];
+    if (grp != NONE) {
+        const uint32_t id = (uint32_t)grp;
+        const int i = l & 15;
+        const int row = (int)(id >> 1) * 32 + 8 * (i >> 2) + 4 * (int)(id & 1) + (i & 3);
+        if (row < job.n_train) {
+            const int* qp = (const int*)(job.q_desc + (size_t)q * DIM);
+            const int* tp = (const int*)(job.t_desc + (size_t)row * DIM);
+            int tt = 0, qt = 0;
+#pragma unroll
+            for (int w = 0; w < DIM / 4; ++w) {
+                const int tv = tp[w];
+                tt = __builtin_amdgcn_sdot4(tv, tv, tt, false);
+                qt = __builtin_amdgcn_sdot4(qp[w], tv, qt, false);
+            }
+            const int d2 = qn + tt - 2 * qt;
+            e = ((u64)(uint32_t)d2 << 32) | (uint32_t)row;
+        }
+    }
+    u64 e1 = e, e2 = NONE;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+        const u64 b1 = __shfl_xor(e1, off), b2 = __shfl_xor(e2, off);
+        const bool afirst = e1 < b1;
+        const u64 f = afirst ? e1 : b1;
+        const u64 s = afirst ? (b1 < e2 ? b1 : e2) : (e1 < b2 ? e1 : b2);
+        e1 = f;
+        e2 = s;
+    }
+    if (l != 0) return;
+    const u64 ee[2] = {e1, e2};
     int cnt = 0;
-    bool redo = false;
-    const unsigned long long e[2] = {f, s};
     for (int j = 0; j < k; ++j) {
         sfm_gpu_dmatch m;
         m.queryIdx = q;
         m.imgIdx = 0;
-        const uint32_t key = (uint32_t)(e[j] >> 32);
-        const int32_t idx = (int32_t)(uint32_t)e[j];
-        if (key != KEY_NONE && idx >= 0 && idx < job.n_train) {
-            const int32_t d2 = qn + (int32_t)key - 2 * KEY_OFFSET;
-            m.trainIdx = idx;
-            m.distance = sqrt_exact_u32((uint32_t)d2);
-            // From 2^22 upwards different integers can share one float sqrt,
-            // and the ranking is defined on the float: re-rank those queries.
-            if (j == 1 && d2 >= (1 << 22)) redo = true;
+        if (ee[j] != NONE) {
+            m.trainIdx = (int32_t)(uint32_t)ee[j];
+            m.distance = sqrt_exact_u32((uint32_t)(ee[j] >> 32));
             cnt++;
         } else {
             m.trainIdx = -1;
@@ -420,18 +379,14 @@ knn_finalize_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k)
         }
         job.out[(size_t)q * k + j] = m;
     }
-    // with k == 1 the second neighbour still decides whether rank 1 is safe
-    if (k == 1) {
-        const uint32_t key2 = (uint32_t)(s >> 32);
-        const int32_t idx2 = (int32_t)(uint32_t)s;
-        if (key2 != KEY_NONE && idx2 >= 0 && idx2 < job.n_train &&
-            qn + (int32_t)key2 - 2 * KEY_OFFSET >= (1 << 22))
-            redo = true;
-    }
     job.counts[q] = cnt;
-    if (redo) {
-        const int slot = atomicAdd(job.redo, 1);
-        job.redo[1 + slot] = q;
+    if (e2 != NONE) {
+        const int32_t d2 = (int32_t)(uint32_t)(e2 >> 32);
+        const uint32_t x2 = (uint32_t)(d2 - qn + 2 * KEY_OFFSET) >> 1;
+        if (d2 >= (1 << 22) || third_x <= x2) {
+            const int slot = atomicAdd(job.redo, 1);
+            job.redo[1 + slot] = q;
+        }
     }
 }
 
@@ -542,10 +497,12 @@ KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant
     p.q_per_block = kVariantQPB[p.variant];
     const int t_chunks = (n_train_max + CHUNK - 1) / CHUNK;
     const long long qblocks = (long long)((n_query_max + p.q_per_block - 1) / p.q_per_block) * n_jobs;
-    // The train sweep is split only as far as needed to give every CU work:
-    // short sweeps start with cold top-2 thresholds and update far more often.
-    int splits = 1;
-    while (qblocks * splits < 256 && splits * 2 <= t_chunks && t_chunks / (splits * 2) >= 4)
+    // The sweep carries no data-dependent state between tiles, so the train rows
+    // can be split freely: enough parts to give every CU two workgroups, and
+    // never more than MAX_SWEEP_CHUNKS chunks per part.
+    int splits = (t_chunks + MAX_SWEEP_CHUNKS - 1) / MAX_SWEEP_CHUNKS;
+    if (splits < 1) splits = 1;
+    while (qblocks * splits < 512 && splits * 2 <= t_chunks && t_chunks / (splits * 2) >= 2)
         splits *= 2;
     p.n_splits = splits;
     p.chunks_per_split = (t_chunks + splits - 1) / splits;
@@ -561,19 +518,19 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
     const dim3 grid(qblocks, plan.n_splits, n_jobs);
     switch (plan.variant) {
         case 1:
-            hipLaunchKernelGGL((knn2_mfma_kernel<2, 4>), grid, dim3(256), 0, s, jobs_dev, plan.n_splits,
+            hipLaunchKernelGGL((knn2_mfma_kernel<2, 4>), grid, dim3(256), 0, s, jobs_dev,
                                plan.chunks_per_split, plan.ablate);
             break;
         case 2:
-            hipLaunchKernelGGL((knn2_mfma_kernel<2, 8>), grid, dim3(512), 0, s, jobs_dev, plan.n_splits,
+            hipLaunchKernelGGL((knn2_mfma_kernel<2, 8>), grid, dim3(512), 0, s, jobs_dev,
                                plan.chunks_per_split, plan.ablate);
             break;
         case 3:
-            hipLaunchKernelGGL((knn2_mfma_kernel<4, 8>), grid, dim3(512), 0, s, jobs_dev, plan.n_splits,
+            hipLaunchKernelGGL((knn2_mfma_kernel<4, 8>), grid, dim3(512), 0, s, jobs_dev,
                                plan.chunks_per_split, plan.ablate);
             break;
         default:
-            hipLaunchKernelGGL((knn2_mfma_kernel<4, 4>), grid, dim3(256), 0, s, jobs_dev, plan.n_splits,
+            hipLaunchKernelGGL((knn2_mfma_kernel<4, 4>), grid, dim3(256), 0, s, jobs_dev,
                                plan.chunks_per_split, plan.ablate);
             break;
     }
@@ -583,8 +540,8 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
 hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_query_max,
                                int n_splits, int k)
 {
-    const dim3 grid((n_query_max + 255) / 256, n_jobs);
-    hipLaunchKernelGGL(knn_finalize_kernel, grid, dim3(256), 0, s, jobs_dev, n_splits, k);
+    const dim3 grid((n_query_max + 7) / 8, n_jobs);
+    hipLaunchKernelGGL(knn_rescan_kernel, grid, dim3(256), 0, s, jobs_dev, n_splits, k);
     return hipGetLastError();
 }
 

@@ -396,7 +396,7 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
                                       std::max<size_t>(1, ((size_t)3 << 30) / (per_pair_ransac + 1)));
     group = std::min(group, 256);
     const KnnPlan plan_probe = plan_knn(nq_max, nt_max, group, ctx->knn_variant);
-    const size_t partial_b = align_up((size_t)plan_probe.n_splits * qalloc_max * sizeof(uint4), 256);
+    const size_t partial_b = align_up((size_t)plan_probe.n_splits * qalloc_max * 2 * sizeof(uint4), 256);
     const size_t out_b = align_up((size_t)nq_max * 2 * sizeof(sfm_gpu_dmatch), 256);
     const size_t cnt_b = align_up((size_t)nq_max * 4, 256);
     const size_t redo_b = align_up(((size_t)nq_max + 1) * 4, 256);
@@ -407,8 +407,6 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
     SFM_HIP(ctx, ctx->out.reserve(out_b * group));
     SFM_HIP(ctx, ctx->counts.reserve(cnt_b * group));
     SFM_HIP(ctx, ctx->redo.reserve(redo_b * group));
-    const size_t thr_b = align_up((size_t)qalloc_max * 4, 256);
-    SFM_HIP(ctx, ctx->thrglob.reserve(thr_b * group));
     SFM_HIP(ctx, ctx->mp_good.reserve((good_b + inl_b) * group));
     SFM_HIP(ctx, ctx->mp_pts.reserve(px_b * 2 * group));
     SFM_HIP(ctx, ctx->mp_ngood.reserve(256 * (size_t)group));
@@ -433,13 +431,11 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
             j.q_desc = q.desc;
             j.t_desc = t.desc;
             j.t_cin = t.cin;
-            j.t_low = t.low;
             j.q_qn = q.qn;
             j.partial = (uint4*)(ctx->partial.as<char>() + partial_b * i);
             j.out = (sfm_gpu_dmatch*)(ctx->out.as<char>() + out_b * i);
             j.counts = (int32_t*)(ctx->counts.as<char>() + cnt_b * i);
             j.redo = (int32_t*)(ctx->redo.as<char>() + redo_b * i);
-            j.thr_glob = (uint32_t*)(ctx->thrglob.as<char>() + thr_b * i);
             j.n_query = q.n;
             j.n_train = t.n;
             j.q_rows_alloc = q.rows_alloc;
@@ -466,7 +462,6 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
             pd.mask = pb.mask;
             pd.result = pb.result;
         }
-        if (plan.n_splits > 1) SFM_HIP(ctx, hipMemsetAsync(ctx->thrglob.p, 0x7F, thr_b * g, s));
         KnnJob* djobs = ctx->jobs.as<KnnJob>();
         PairDev* dpds = (PairDev*)(ctx->jobs.as<char>() + sizeof(KnnJob) * (size_t)group);
         SFM_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), sizeof(KnnJob) * g, hipMemcpyHostToDevice, s));

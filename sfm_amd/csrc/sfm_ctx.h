@@ -40,9 +40,9 @@ struct DevBuf {
 };
 
 // Bytes of the device block that holds an image of n rows:
-// [desc rows*128 | cin rows*4 | low rows*4 | qn rows*4 | keypoints rows*8].
+// [desc rows*128 | cin rows*4 | qn rows*4 | keypoints rows*8].
 inline int image_rows_alloc(int n) { return ((n > 0 ? n : 1) + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN; }
-inline size_t image_block_bytes(int n) { return (size_t)image_rows_alloc(n) * (DIM + 12 + 8); }
+inline size_t image_block_bytes(int n) { return (size_t)image_rows_alloc(n) * (DIM + 8 + 8); }
 inline ImageDev image_layout(void* base, int n)
 {
     ImageDev d;
@@ -51,8 +51,7 @@ inline ImageDev image_layout(void* base, int n)
     d.rows_alloc = rows;
     d.desc = (int8_t*)base;
     d.cin = (int32_t*)(d.desc + (size_t)rows * DIM);
-    d.low = d.cin + rows;
-    d.qn = d.low + rows;
+    d.qn = d.cin + rows;
     d.kp = (float2*)(d.qn + rows);
     return d;
 }
@@ -66,15 +65,14 @@ struct ImageStore {
     hipError_t shape(int n, bool with_kp)
     {
         int rows = ((n > 0 ? n : 1) + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN;
-        size_t bytes = (size_t)rows * (DIM + 12);
+        size_t bytes = (size_t)rows * (DIM + 8);
         hipError_t e = buf.reserve(bytes);
         if (e != hipSuccess) return e;
         d.n = n;
         d.rows_alloc = rows;
         d.desc = buf.as<int8_t>();
         d.cin = (int32_t*)(d.desc + (size_t)rows * DIM);
-        d.low = d.cin + rows;
-        d.qn = d.low + rows;
+        d.qn = d.cin + rows;
         d.kp = nullptr;
         if (with_kp) {
             e = kpbuf.reserve((size_t)(n > 0 ? n : 1) * sizeof(float2));
@@ -101,7 +99,7 @@ struct sfm_gpu_ctx {
 
     sfm::DevBuf raw_q, raw_t;
     sfm::ImageStore tmp_q, tmp_t;
-    sfm::DevBuf partial, out, counts, redo, jobs, flags, prepjobs, thrglob;
+    sfm::DevBuf partial, out, counts, redo, jobs, flags, prepjobs;
     // ransac workspaces
     sfm::DevBuf rs_pts, rs_table, rs_models, rs_counts, rs_mask, rs_misc;
     // match_pairs workspaces

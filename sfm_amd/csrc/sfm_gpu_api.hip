@@ -76,7 +76,7 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
     const int nq = q.n, nt = t.n;
     if (nq == 0) return SFM_GPU_OK;
     const KnnPlan plan = plan_knn(nq, nt, 1, ctx->knn_variant);
-    SFM_HIP(ctx, ctx->partial.reserve((size_t)plan.n_splits * q.rows_alloc * sizeof(uint4)));
+    SFM_HIP(ctx, ctx->partial.reserve((size_t)plan.n_splits * q.rows_alloc * 2 * sizeof(uint4)));
     SFM_HIP(ctx, ctx->redo.reserve(((size_t)nq + 1) * 4));
     SFM_HIP(ctx, ctx->jobs.reserve(sizeof(KnnJob)));
     sfm_gpu_dmatch* out_dev = matches;
@@ -91,18 +91,11 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
     job.q_desc = q.desc;
     job.t_desc = t.desc;
     job.t_cin = t.cin;
-    job.t_low = t.low;
     job.q_qn = q.qn;
     job.partial = ctx->partial.as<uint4>();
     job.out = out_dev;
     job.counts = cnt_dev;
     job.redo = ctx->redo.as<int32_t>();
-    SFM_HIP(ctx, ctx->thrglob.reserve((size_t)q.rows_alloc * 4 + 16));
-    job.thr_glob = ctx->thrglob.as<uint32_t>();
-    if (plan.n_splits > 1)
-        SFM_HIP(ctx, hipMemsetAsync(ctx->thrglob.p, 0x7F, (size_t)q.rows_alloc * 4, ctx->stream));
-    if (plan.ablate >= 4)  // statistics words behind the thresholds
-        SFM_HIP(ctx, hipMemsetAsync(ctx->thrglob.as<char>() + (size_t)q.rows_alloc * 4, 0, 16, ctx->stream));
     job.n_query = nq;
     job.n_train = nt;
     job.q_rows_alloc = q.rows_alloc;
@@ -175,7 +168,7 @@ void sfm_gpu_destroy(sfm_gpu_ctx* c)
             (void)hipEventDestroy(pr.second);
         }
     DevBuf* bufs[] = {&c->raw_q, &c->raw_t, &c->partial, &c->out, &c->counts, &c->redo, &c->jobs,
-                      &c->flags, &c->prepjobs, &c->thrglob, &c->rs_pts, &c->rs_table, &c->rs_models, &c->rs_counts, &c->rs_mask,
+                      &c->flags, &c->prepjobs, &c->rs_pts, &c->rs_table, &c->rs_models, &c->rs_counts, &c->rs_mask,
                       &c->rs_misc, &c->mp_good, &c->mp_pts, &c->mp_ngood};
     for (DevBuf* b : bufs) b->release();
     c->tmp_q.release();
@@ -437,18 +430,6 @@ int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* c, int variant)
 {
     if (!c) return SFM_GPU_ERR_ARG;
     c->knn_variant = variant;
-    return SFM_GPU_OK;
-}
-
-// Update-path statistics of the last sfm_gpu_knn_match_images call made with
-// variant >= 64 (ablate 4): {tile checks, update passes, candidate lanes}.
-int sfm_gpu_debug_knn_stats(sfm_gpu_ctx* ctx, int q_rows, uint32_t* out3)
-{
-    if (!ctx || !out3 || !ctx->thrglob.p) return SFM_GPU_ERR_ARG;
-    const int rows = image_rows_alloc(q_rows);
-    SFM_HIP(ctx, hipMemcpyAsync(out3, ctx->thrglob.as<char>() + (size_t)rows * 4, 12, hipMemcpyDeviceToHost,
-                                ctx->stream));
-    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SFM_GPU_OK;
 }
 

@@ -15,15 +15,17 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int DIM = 128;
-// Train rows are swept in chunks of 256: inside a chunk the running top-2 keeps
-// an 8-bit row index packed under the 24-bit distance key.
+// Granule in which the train rows are divided among workgroups.
 constexpr int CHUNK = 256;
+// One workgroup sweeps at most this many chunks (512 tiles of 32 rows: the
+// tile number is packed into 9 bits under the 23-bit x).
+constexpr int MAX_SWEEP_CHUNKS = 64;
 // Descriptor stores are allocated in multiples of this many rows so that every
 // workgroup shape may read whole query blocks and whole train chunks.
 constexpr int ROW_ALIGN = 1024;
 // x = dot + cin is what the MFMA chain leaves in the accumulator.
 // cin = floor(Tn/2) + KEY_OFFSET keeps x in [64, 5226560] for every pair of
-// 0..255-valued rows, so (x << 9) fits 32 bits.
+// 0..255-valued rows: 23 bits, so (x << 9) | tile fits 32 bits.
 constexpr int KEY_OFFSET = 2080896;
 constexpr int PAD_CIN = 0x7FFFFF;  // padding rows rank behind every real row
 constexpr uint32_t KEY_NONE = 0xFFFFFFu;
@@ -32,15 +34,13 @@ constexpr uint32_t KEY_NONE = 0xFFFFFFu;
 //   desc[r][d]  = value - 128 as int8 (byte = value ^ 0x80)
 //   qn[r]       = sum_d (value-128)^2                (query-side norm)
 //   cin[r]      = floor(Tn/2) + KEY_OFFSET, Tn = sum_d (value-127)^2 - 128
-//   low[r]      = (Tn & 1) << 8 | (r & 255)
 // so that for query q and train t:
-//   d2(q,t) = qn[q] + 2*(dot(~q, t) + cin[t]) + (low[t] >> 8) - 2*KEY_OFFSET
+//   d2(q,t) = qn[q] + 2*(dot(~q, t) + cin[t]) + (Tn & 1) - 2*KEY_OFFSET
 struct ImageDev {
     int n = 0;
     int rows_alloc = 0;
     int8_t* desc = nullptr;
     int32_t* cin = nullptr;
-    int32_t* low = nullptr;
     int32_t* qn = nullptr;
     float2* kp = nullptr;
 };
@@ -58,13 +58,11 @@ struct KnnJob {
     const int8_t* q_desc;
     const int8_t* t_desc;
     const int32_t* t_cin;
-    const int32_t* t_low;
     const int32_t* q_qn;
-    uint4* partial;       // [n_splits][q_rows_alloc] {key1, idx1, key2, idx2}
+    uint4* partial;       // [n_splits][q_rows_alloc][2] {best group, 2nd group, 3rd minimum, first tile}
     sfm_gpu_dmatch* out;  // [n_query][k]
     int32_t* counts;      // [n_query]
     int32_t* redo;        // [0] = count, [1..] = query rows needing the float-ranked pass
-    uint32_t* thr_glob;   // [q_rows_alloc] shared second-best bounds (split sweeps), preset to >= 0x7FFFFF
     int n_query;
     int n_train;
     int q_rows_alloc;
