@@ -248,17 +248,40 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int abla
         compute_tile(f1, tile0 + 3);
     }
 
-    // one record per (split, query, lane half): best two groups, third minimum,
-    // global index of the sweep's first tile
+    // Lanes l and l+32 hold the same query over disjoint groups: merge their
+    // triples; lane l < 32 writes one record per (split, query):
+    //   x = best group (x << 9 | tile), y = second group, z = third minimum,
+    //   w = first tile of the sweep | half of best << 30 | half of second << 31
     static_for<QB>([&](auto qbc) {
         constexpr int qb = decltype(qbc)::value;
-        const int q = q_base + qb * 32 + col;
-        uint4 o;
-        o.x = m1[qb];
-        o.y = m2[qb];
-        o.z = m3[qb];
-        o.w = (uint32_t)(c0 * (CHUNK / 32));
-        job.partial[((size_t)blockIdx.y * job.q_rows_alloc + q) * 2 + h] = o;
+        typedef unsigned long long u64;
+        const u64 NONE = ~0ull;
+        auto key = [&](uint32_t p, int hh) -> u64 {
+            return p == 0xFFFFFFFFu ? NONE : (((u64)p << 1) | (u64)hh);
+        };
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)m1[qb], 32);
+        const uint32_t o2 = (uint32_t)__shfl_xor((int)m2[qb], 32);
+        const uint32_t o3 = (uint32_t)__shfl_xor((int)m3[qb], 32);
+        u64 c1 = key(m1[qb], h), c2 = key(m2[qb], h), c3 = key(m3[qb], h);
+        const u64 b[3] = {key(o1, h ^ 1), key(o2, h ^ 1), key(o3, h ^ 1)};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const u64 v = b[j];
+            if (v < c3) {
+                c3 = v;
+                if (c3 < c2) { const u64 t = c2; c2 = c3; c3 = t; }
+                if (c2 < c1) { const u64 t = c1; c1 = c2; c2 = t; }
+            }
+        }
+        if (h == 0) {
+            const int q = q_base + qb * 32 + col;
+            uint4 o;
+            o.x = c1 == NONE ? 0xFFFFFFFFu : (uint32_t)(c1 >> 1);
+            o.y = c2 == NONE ? 0xFFFFFFFFu : (uint32_t)(c2 >> 1);
+            o.z = c3 == NONE ? 0xFFFFFFFFu : (uint32_t)(c3 >> 1);
+            o.w = (uint32_t)(c0 * (CHUNK / 32)) | ((uint32_t)(c1 & 1) << 30) | ((uint32_t)(c2 & 1) << 31);
+            job.partial[(size_t)blockIdx.y * job.q_rows_alloc + q] = o;
+        }
     });
 }
 
@@ -270,7 +293,7 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int abla
 __device__ __forceinline__ float sqrt_exact_u32(uint32_t n)
 {
     const double dn = (double)n;
-    float f = (float)sqrt(dn);
+    float f = sqrtf((float)n);  // n < 2^24 is exact in float
     if (n == 0) return 0.f;
     const float up = __uint_as_float(__float_as_uint(f) + 1u);
     const float dnf = __uint_as_float(__float_as_uint(f) - 1u);
@@ -294,11 +317,11 @@ __device__ __forceinline__ void insert3(u64& a1, u64& a2, u64& a3, u64 v)
 }
 
 // Exact neighbours from the sweep records.  32 lanes per query:
-//  1. the query's records (2 lane halves x n_splits) are reduced to the two
-//     best groups by (minimum x, tile, half) and to the smallest x of all the
-//     other groups;
-//  2. lane l computes the exact squared distance to row l%16 of group l/16;
-//  3. the two smallest (d2, row) are the neighbours.  Every row outside the two
+//  1. the query's records (one per split) are reduced to the two best groups
+//     by (minimum x, tile, half) and to the smallest x of all the other groups;
+//  2. the 32 rows of the two groups are laid over the 32 lanes in ascending row
+//     order and every lane computes the exact squared distance of its row;
+//  3. the two smallest (d2, lane) are the neighbours.  Every row outside the two
 //     groups has x >= the third minimum, hence d2-key >= 2*third; if that does
 //     not exceed the key of the second neighbour found (a tie between group
 //     minima), or if d2 >= 2^22 where different d2 share one float sqrt, the
@@ -311,77 +334,128 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k)
     const int l = threadIdx.x & 31;
     if (q >= job.n_query) return;  // whole 32-lane group leaves together
     const u64 NONE = ~0ull;
+    const uint32_t tmask = (1u << TILE_BITS) - 1u;
     u64 c1 = NONE, c2 = NONE, c3 = NONE;
-    for (int j = l; j < 2 * n_splits; j += 32) {
-        const int sp = j >> 1, hh = j & 1;
-        const uint4 r = job.partial[((size_t)sp * job.q_rows_alloc + q) * 2 + hh];
-        const uint32_t tmask = (1u << TILE_BITS) - 1u;
+    auto take = [&](const uint4 r) {
+        const uint32_t t0 = r.w & 0x3FFFFFFFu;
         if (r.x != 0xFFFFFFFFu)
-            insert3(c1, c2, c3, ((u64)(r.x >> TILE_BITS) << 32) | (((r.w + (r.x & tmask)) << 1) | hh));
+            insert3(c1, c2, c3, ((u64)(r.x >> TILE_BITS) << 32) | (((t0 + (r.x & tmask)) << 1) | (r.w >> 30 & 1u)));
         if (r.y != 0xFFFFFFFFu)
-            insert3(c1, c2, c3, ((u64)(r.y >> TILE_BITS) << 32) | (((r.w + (r.y & tmask)) << 1) | hh));
+            insert3(c1, c2, c3, ((u64)(r.y >> TILE_BITS) << 32) | (((t0 + (r.y & tmask)) << 1) | (r.w >> 31)));
         if (r.z != 0xFFFFFFFFu) insert3(c1, c2, c3, ((u64)(r.z >> TILE_BITS) << 32) | 0xFFFFFFFFu);
-    }
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-        const u64 b1 = __shfl_xor(c1, off), b2 = __shfl_xor(c2, off), b3 = __shfl_xor(c3, off);
-        insert3(c1, c2, c3, b1);
-        insert3(c1, c2, c3, b2);
-        insert3(c1, c2, c3, b3);
-    }
-    // every lane now holds the same c1 <= c2 <= c3
-    const u64 grp = (l < 16) ? c1 : c2;
-    const uint32_t third_x = (uint32_t)(c3 >> 32);  // 0xFFFFFFFF when there is no third group
-    u64 e = NONE;
-    const int qn = job.q_qn[q];
-    if (grp != NONE) {
-        const uint32_t id = (uint32_t)grp;
-        const int i = l & 15;
-        const int row = (int)(id >> 1) * 32 + 8 * (i >> 2) + 4 * (int)(id & 1) + (i & 3);
-        if (row < job.n_train) {
-            const int* qp = (const int*)(job.q_desc + (size_t)q * DIM);
-            const int* tp = (const int*)(job.t_desc + (size_t)row * DIM);
-            int tt = 0, qt = 0;
-#pragma unroll
-            for (int w = 0; w < DIM / 4; ++w) {
-                const int tv = tp[w];
-                tt = __builtin_amdgcn_sdot4(tv, tv, tt, false);
-                qt = __builtin_amdgcn_sdot4(qp[w], tv, qt, false);
-            }
-            const int d2 = qn + tt - 2 * qt;
-            e = ((u64)(uint32_t)d2 << 32) | (uint32_t)row;
+    };
+    if (n_splits == 1) {
+        take(job.partial[q]);
+    } else {
+        for (int j = l; j < n_splits; j += 32) take(job.partial[(size_t)j * job.q_rows_alloc + q]);
+        for (int off = 1; off < 32 && off < n_splits; off <<= 1) {
+            const u64 b1 = __shfl_xor(c1, off), b2 = __shfl_xor(c2, off), b3 = __shfl_xor(c3, off);
+            insert3(c1, c2, c3, b1);
+            insert3(c1, c2, c3, b2);
+            insert3(c1, c2, c3, b3);
         }
+        // lanes 0 .. pow2(n_splits)-1 agree; spread lane 0's result
+        c1 = __shfl(c1, 0, 32);
+        c2 = __shfl(c2, 0, 32);
+        c3 = __shfl(c3, 0, 32);
     }
-    u64 e1 = e, e2 = NONE;
+    const uint32_t third_x = (uint32_t)(c3 >> 32);  // 0xFFFFFFFF when there is no third group
+    // c1 < c2 compares (x, tile, half).  For the lane order to be the row order
+    // the group with the smaller (tile, half) must come first.
+    const uint32_t ida = (uint32_t)c1, idb = (uint32_t)c2;
+    const bool have_a = c1 != NONE, have_b = c2 != NONE;
+    const uint32_t id_lo = (!have_b || ida < idb) ? ida : idb;
+    const uint32_t id_hi = (!have_b || ida < idb) ? idb : ida;
+    const bool same_tile = have_b && (id_lo >> 1) == (id_hi >> 1);
+    // candidate position 0..31 -> train row (ascending), -1 when there is none
+    auto row_of = [&](int pos) -> int {
+        if (!have_a) return -1;
+        if (same_tile) return (int)(id_lo >> 1) * 32 + pos;  // both halves of one tile
+        if (pos >= 16 && !have_b) return -1;
+        const uint32_t id = pos < 16 ? id_lo : id_hi;
+        const int i = pos & 15;
+        return (int)(id >> 1) * 32 + 8 * (i >> 2) + 4 * (int)(id & 1) + (i & 3);
+    };
+    // Dot products, 8 lanes per row so that each load instruction fetches whole
+    // 128-B rows: lane l works on 16-byte segment l&7 of candidates 4*it + (l>>3).
+    // All loads are issued up front on clamped rows (padding rows are readable)
+    // so that none of them waits behind another's latency; rows that do not
+    // exist are masked out at the end.
+    const int sg = l & 7, rq = l >> 3;
+    const int pos = 4 * sg + rq;
+    const int row = row_of(pos);
+    const bool row_ok = row >= 0 && row < job.n_train;
+    const int qn = job.q_qn[q];
+    const int tn = job.t_qn[row_ok ? row : 0];
+    const v4i qv = *(const v4i*)(job.q_desc + (size_t)q * DIM + sg * 16);
+    v4i tv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int r = row_of(it * 4 + rq);
+        tv[it] = *(const v4i*)(job.t_desc + (size_t)(r < 0 ? 0 : r) * DIM + sg * 16);
+    }
+    int part[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        int acc = __builtin_amdgcn_sdot4(qv[0], tv[it][0], 0, false);
+        acc = __builtin_amdgcn_sdot4(qv[1], tv[it][1], acc, false);
+        acc = __builtin_amdgcn_sdot4(qv[2], tv[it][2], acc, false);
+        acc = __builtin_amdgcn_sdot4(qv[3], tv[it][3], acc, false);
+        part[it] = acc;
+    }
+    // reduce over the 8 segments while scattering the 8 candidates: afterwards
+    // lane l holds the whole dot product of candidate 4*sg + rq
+    int r4[4], r2[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool up = (sg & 4) != 0;
+        const int mine = up ? part[j + 4] : part[j];
+        const int send = up ? part[j] : part[j + 4];
+        r4[j] = mine + __shfl_xor(send, 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const bool up = (sg & 2) != 0;
+        const int mine = up ? r4[j + 2] : r4[j];
+        const int send = up ? r4[j] : r4[j + 2];
+        r2[j] = mine + __shfl_xor(send, 2);
+    }
+    const int qt = ((sg & 1) ? r2[1] : r2[0]) + __shfl_xor((sg & 1) ? r2[0] : r2[1], 1);
+    uint32_t e = 0xFFFFFFFFu;  // (d2 << 5) | position; d2 <= 8323200 < 2^23
+    if (row_ok) {
+        const int d2 = qn + tn - 2 * qt;
+        e = ((uint32_t)d2 << 5) | (uint32_t)pos;
+    }
+    // two smallest over the 32 lanes
+    uint32_t e1 = e, e2 = 0xFFFFFFFFu;
 #pragma unroll
     for (int off = 1; off < 32; off <<= 1) {
-        const u64 b1 = __shfl_xor(e1, off), b2 = __shfl_xor(e2, off);
-        const bool afirst = e1 < b1;
-        const u64 f = afirst ? e1 : b1;
-        const u64 s = afirst ? (b1 < e2 ? b1 : e2) : (e1 < b2 ? e1 : b2);
-        e1 = f;
-        e2 = s;
+        const uint32_t b1 = (uint32_t)__shfl_xor((int)e1, off), b2 = (uint32_t)__shfl_xor((int)e2, off);
+        const uint32_t lo = umin32(e1, b1);
+        e2 = umin32(umax32(e1, b1), umin32(e2, b2));
+        e1 = lo;
     }
-    if (l != 0) return;
-    const u64 ee[2] = {e1, e2};
-    int cnt = 0;
-    for (int j = 0; j < k; ++j) {
+    const int row1 = row_of((int)(e1 & 31u));
+    const int row2 = row_of((int)(e2 & 31u));
+    // lane j < k writes neighbour j
+    if (l < k) {
+        const uint32_t ej = l == 0 ? e1 : e2;
         sfm_gpu_dmatch m;
         m.queryIdx = q;
         m.imgIdx = 0;
-        if (ee[j] != NONE) {
-            m.trainIdx = (int32_t)(uint32_t)ee[j];
-            m.distance = sqrt_exact_u32((uint32_t)(ee[j] >> 32));
-            cnt++;
+        if (ej != 0xFFFFFFFFu) {
+            m.trainIdx = l == 0 ? row1 : row2;
+            m.distance = sqrt_exact_u32(ej >> 5);
         } else {
             m.trainIdx = -1;
             m.distance = __uint_as_float(0x7f7fffffu);  // FLT_MAX
         }
-        job.out[(size_t)q * k + j] = m;
+        job.out[(size_t)q * k + l] = m;
     }
-    job.counts[q] = cnt;
-    if (e2 != NONE) {
-        const int32_t d2 = (int32_t)(uint32_t)(e2 >> 32);
+    if (l != 0) return;
+    job.counts[q] = (e1 != 0xFFFFFFFFu ? 1 : 0) + ((k > 1 && e2 != 0xFFFFFFFFu) ? 1 : 0);
+    if (e2 != 0xFFFFFFFFu) {
+        const int32_t d2 = (int32_t)(e2 >> 5);
         const uint32_t x2 = (uint32_t)(d2 - qn + 2 * KEY_OFFSET) >> 1;
         if (d2 >= (1 << 22) || third_x <= x2) {
             const int slot = atomicAdd(job.redo, 1);
@@ -498,11 +572,11 @@ KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant
     const int t_chunks = (n_train_max + CHUNK - 1) / CHUNK;
     const long long qblocks = (long long)((n_query_max + p.q_per_block - 1) / p.q_per_block) * n_jobs;
     // The sweep carries no data-dependent state between tiles, so the train rows
-    // can be split freely: enough parts to give every CU two workgroups, and
+    // can be split freely: enough parts to give every CU a workgroup, and
     // never more than MAX_SWEEP_CHUNKS chunks per part.
     int splits = (t_chunks + MAX_SWEEP_CHUNKS - 1) / MAX_SWEEP_CHUNKS;
     if (splits < 1) splits = 1;
-    while (qblocks * splits < 512 && splits * 2 <= t_chunks && t_chunks / (splits * 2) >= 2)
+    while (qblocks * splits < 256 && splits * 2 <= t_chunks && t_chunks / (splits * 2) >= 2)
         splits *= 2;
     p.n_splits = splits;
     p.chunks_per_split = (t_chunks + splits - 1) / splits;

@@ -396,7 +396,7 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
                                       std::max<size_t>(1, ((size_t)3 << 30) / (per_pair_ransac + 1)));
     group = std::min(group, 256);
     const KnnPlan plan_probe = plan_knn(nq_max, nt_max, group, ctx->knn_variant);
-    const size_t partial_b = align_up((size_t)plan_probe.n_splits * qalloc_max * 2 * sizeof(uint4), 256);
+    const size_t partial_b = align_up((size_t)plan_probe.n_splits * qalloc_max * sizeof(uint4), 256);
     const size_t out_b = align_up((size_t)nq_max * 2 * sizeof(sfm_gpu_dmatch), 256);
     const size_t cnt_b = align_up((size_t)nq_max * 4, 256);
     const size_t redo_b = align_up(((size_t)nq_max + 1) * 4, 256);
@@ -432,6 +432,7 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
             j.t_desc = t.desc;
             j.t_cin = t.cin;
             j.q_qn = q.qn;
+            j.t_qn = t.qn;
             j.partial = (uint4*)(ctx->partial.as<char>() + partial_b * i);
             j.out = (sfm_gpu_dmatch*)(ctx->out.as<char>() + out_b * i);
             j.counts = (int32_t*)(ctx->counts.as<char>() + cnt_b * i);

@@ -76,7 +76,7 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
     const int nq = q.n, nt = t.n;
     if (nq == 0) return SFM_GPU_OK;
     const KnnPlan plan = plan_knn(nq, nt, 1, ctx->knn_variant);
-    SFM_HIP(ctx, ctx->partial.reserve((size_t)plan.n_splits * q.rows_alloc * 2 * sizeof(uint4)));
+    SFM_HIP(ctx, ctx->partial.reserve((size_t)plan.n_splits * q.rows_alloc * sizeof(uint4)));
     SFM_HIP(ctx, ctx->redo.reserve(((size_t)nq + 1) * 4));
     SFM_HIP(ctx, ctx->jobs.reserve(sizeof(KnnJob)));
     sfm_gpu_dmatch* out_dev = matches;
@@ -92,6 +92,7 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
     job.t_desc = t.desc;
     job.t_cin = t.cin;
     job.q_qn = q.qn;
+    job.t_qn = t.qn;
     job.partial = ctx->partial.as<uint4>();
     job.out = out_dev;
     job.counts = cnt_dev;

@@ -59,7 +59,8 @@ struct KnnJob {
     const int8_t* t_desc;
     const int32_t* t_cin;
     const int32_t* q_qn;
-    uint4* partial;       // [n_splits][q_rows_alloc][2] {best group, 2nd group, 3rd minimum, first tile}
+    const int32_t* t_qn;
+    uint4* partial;       // [n_splits][q_rows_alloc] {best group, 2nd group, 3rd minimum, first tile | halves}
     sfm_gpu_dmatch* out;  // [n_query][k]
     int32_t* counts;      // [n_query]
     int32_t* redo;        // [0] = count, [1..] = query rows needing the float-ranked pass
