@@ -15,6 +15,10 @@ extern "C" {
 /* Forces the workgroup shape of the distance kernel (-1: planner decides). */
 int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* ctx, int variant);
 
+/* Number of queries that the last k-NN call on this context (its first job)
+ * sent through the exhaustive float-ranked pass. */
+int sfm_gpu_debug_redo_count(sfm_gpu_ctx* ctx, int32_t* out);
+
 /* c[32][32] (int32) = a[32][32] * b^T with b given as [32 columns][32 k], all
  * host pointers, through one v_mfma_i32_32x32x32_i8 loaded the way the
  * distance kernel loads its operands. */

@@ -88,6 +88,7 @@ def lib():
     L.sfm_gpu_profile_query.argtypes = [vp, c.c_char_p, c.POINTER(c.c_double),
                                         c.POINTER(c.c_int64)]
     L.sfm_gpu_debug_set_knn_variant.argtypes = [vp, c.c_int]
+    L.sfm_gpu_debug_redo_count.argtypes = [vp, vp]
     L.sfm_gpu_debug_mfma_probe.argtypes = [vp, vp, vp, vp]
     L.sfm_gpu_debug_ransac_dump.argtypes = [vp, c.c_int, vp, vp, vp, vp]
     _lib = L

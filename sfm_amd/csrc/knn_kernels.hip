@@ -466,59 +466,118 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k)
 
 // Float-ranked exhaustive pass for the queries flagged above: ranks train rows
 // by (sqrtf(d2) as float, row), exactly the reference ordering, at any d2.
-__global__ void __launch_bounds__(256) knn_redo_kernel(const KnnJob* __restrict__ jobs, int k)
+// Each flagged query is cut into segments of train rows handled by different
+// workgroups (knn_redo_scan_kernel, partial results parked in the sweep's
+// record buffer, which is free by now) and merged by knn_redo_merge_kernel.
+// 8 lanes share a row so that each load instruction fetches whole 128-B rows.
+constexpr int REDO_MAX_SEG = 64;
+
+__device__ __forceinline__ int redo_segments(const KnnJob& job, int n_redo, int n_splits)
 {
-    __shared__ unsigned long long sh[2 * 256];
+    const long long cap = (long long)job.q_rows_alloc * n_splits;  // uint4 slots in job.partial
+    long long nseg = n_redo > 0 ? cap / n_redo : 1;
+    if (nseg > REDO_MAX_SEG) nseg = REDO_MAX_SEG;
+    return nseg < 1 ? 1 : (int)nseg;
+}
+
+__device__ __forceinline__ void merge2(u64& a1, u64& a2, u64 b1, u64 b2)
+{
+    const bool afirst = a1 < b1;
+    const u64 nf = afirst ? a1 : b1;
+    const u64 ns = afirst ? (b1 < a2 ? b1 : a2) : (a1 < b2 ? a1 : b2);
+    a1 = nf;
+    a2 = ns;
+}
+
+__global__ void __launch_bounds__(256)
+knn_redo_scan_kernel(const KnnJob* __restrict__ jobs, int n_splits)
+{
+    __shared__ u64 sh[2 * 4];
     const KnnJob job = jobs[blockIdx.y];
     const int n_redo = job.redo[0];
-    for (int item = blockIdx.x; item < n_redo; item += gridDim.x) {
+    if (n_redo == 0) return;
+    const int nseg = redo_segments(job, n_redo, n_splits);
+    const int seg_rows = ((job.n_train + nseg - 1) / nseg + 31) & ~31;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sg = lane & 7, rsub = lane >> 3;
+    const u64 NONE = ~0ull;
+    for (int u = blockIdx.x; u < n_redo * nseg; u += gridDim.x) {
+        const int item = u / nseg, seg = u - item * nseg;
         const int q = job.redo[1 + item];
-        const int8_t* qrow = job.q_desc + (size_t)q * DIM;
-        unsigned long long f = ~0ull, s = ~0ull;
-        for (int t = threadIdx.x; t < job.n_train; t += 256) {
-            const int8_t* trow = job.t_desc + (size_t)t * DIM;
-            int d2 = 0;
-            for (int d = 0; d < DIM; d += 4) {
-                const int qa = *(const int*)(qrow + d);
-                const int ta = *(const int*)(trow + d);
+        const int r0 = seg * seg_rows;
+        const int r1 = min(r0 + seg_rows, job.n_train);
+        const v4i qv = *(const v4i*)(job.q_desc + (size_t)q * DIM + sg * 16);
+        const int qn = job.q_qn[q];
+        u64 f = NONE, s = NONE;
+        int d2f = 0x7FFFFFFF, lim = 0x7FFFFFFF;  // d2 of this lane's best / second best so far
+        for (int base = r0 + wave * 8; base < r1; base += 4 * 8) {
+            const int row = base + rsub;
+            const bool ok = row < r1;
+            const int rr = ok ? row : 0;
+            const v4i tv = *(const v4i*)(job.t_desc + (size_t)rr * DIM + sg * 16);
+            const int tn = job.t_qn[rr];
+            int acc = __builtin_amdgcn_sdot4(qv[0], tv[0], 0, false);
+            acc = __builtin_amdgcn_sdot4(qv[1], tv[1], acc, false);
+            acc = __builtin_amdgcn_sdot4(qv[2], tv[2], acc, false);
+            acc = __builtin_amdgcn_sdot4(qv[3], tv[3], acc, false);
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 4);
+            const int d2 = qn + tn - 2 * acc;
+            // rows come in ascending order, so a later row needs a float distance
+            // strictly below the second best's, hence a smaller d2
+            if (ok && sg == 0 && d2 < lim) {
+                const u64 key = ((u64)__float_as_uint(sqrt_exact_u32((uint32_t)d2)) << 32) | (uint32_t)row;
+                if (key < f) { s = f; f = key; lim = d2f; d2f = d2; }
+                else if (key < s) { s = key; lim = d2; }
+            }
+        }
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int df = (int)(int8_t)(qa >> (8 * b)) - (int)(int8_t)(ta >> (8 * b));
-                    d2 += df * df;
-                }
-            }
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(sqrt_exact_u32((uint32_t)d2)) << 32) | (uint32_t)t;
-            if (key < f) { s = f; f = key; }
-            else if (key < s) { s = key; }
+        for (int off = 1; off < 64; off <<= 1) merge2(f, s, __shfl_xor(f, off), __shfl_xor(s, off));
+        if (lane == 0) {
+            sh[2 * wave] = f;
+            sh[2 * wave + 1] = s;
         }
-        sh[2 * threadIdx.x] = f;
-        sh[2 * threadIdx.x + 1] = s;
         __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) {
-                const unsigned long long a1 = sh[2 * threadIdx.x], a2 = sh[2 * threadIdx.x + 1];
-                const unsigned long long b1 = sh[2 * (threadIdx.x + off)], b2 = sh[2 * (threadIdx.x + off) + 1];
-                const bool afirst = a1 < b1;
-                sh[2 * threadIdx.x] = afirst ? a1 : b1;
-                sh[2 * threadIdx.x + 1] = afirst ? (b1 < a2 ? b1 : a2) : (a1 < b2 ? a1 : b2);
-            }
-            __syncthreads();
-        }
         if (threadIdx.x == 0) {
-            for (int j = 0; j < k; ++j) {
-                const unsigned long long e = sh[j];
-                if (e != ~0ull) {
-                    sfm_gpu_dmatch m;
-                    m.queryIdx = q;
-                    m.imgIdx = 0;
-                    m.trainIdx = (int32_t)(uint32_t)e;
-                    m.distance = __uint_as_float((uint32_t)(e >> 32));
-                    job.out[(size_t)q * k + j] = m;
-                }
-            }
+            u64 a1 = NONE, a2 = NONE;
+            for (int w = 0; w < 4; ++w) merge2(a1, a2, sh[2 * w], sh[2 * w + 1]);
+            uint4 o;
+            o.x = (uint32_t)a1;
+            o.y = (uint32_t)(a1 >> 32);
+            o.z = (uint32_t)a2;
+            o.w = (uint32_t)(a2 >> 32);
+            job.partial[u] = o;
         }
         __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+knn_redo_merge_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k)
+{
+    const KnnJob job = jobs[blockIdx.y];
+    const int n_redo = job.redo[0];
+    const int nseg = redo_segments(job, n_redo, n_splits);
+    const u64 NONE = ~0ull;
+    for (int item = blockIdx.x * 256 + threadIdx.x; item < n_redo; item += gridDim.x * 256) {
+        const int q = job.redo[1 + item];
+        u64 a1 = NONE, a2 = NONE;
+        for (int seg = 0; seg < nseg; ++seg) {
+            const uint4 o = job.partial[(size_t)item * nseg + seg];
+            merge2(a1, a2, ((u64)o.y << 32) | o.x, ((u64)o.w << 32) | o.z);
+        }
+        const u64 e[2] = {a1, a2};
+        for (int j = 0; j < k; ++j) {
+            if (e[j] != NONE) {
+                sfm_gpu_dmatch m;
+                m.queryIdx = q;
+                m.imgIdx = 0;
+                m.trainIdx = (int32_t)(uint32_t)e[j];
+                m.distance = __uint_as_float((uint32_t)(e[j] >> 32));
+                job.out[(size_t)q * k + j] = m;
+            }
+        }
     }
 }
 
@@ -619,9 +678,10 @@ hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs
     return hipGetLastError();
 }
 
-hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int k)
+hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_splits, int k)
 {
-    hipLaunchKernelGGL(knn_redo_kernel, dim3(32, n_jobs), dim3(256), 0, s, jobs_dev, k);
+    hipLaunchKernelGGL(knn_redo_scan_kernel, dim3(512, n_jobs), dim3(256), 0, s, jobs_dev, n_splits);
+    hipLaunchKernelGGL(knn_redo_merge_kernel, dim3(4, n_jobs), dim3(256), 0, s, jobs_dev, n_splits, k);
     return hipGetLastError();
 }
 

@@ -477,7 +477,7 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
         }
         {
             ProfScope ps(ctx, "knn_redo");
-            SFM_HIP(ctx, launch_knn_redo(s, djobs, g, 2));
+            SFM_HIP(ctx, launch_knn_redo(s, djobs, g, plan.n_splits, 2));
         }
         {
             ProfScope ps(ctx, "ratio_compact");

@@ -113,7 +113,7 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
     }
     {
         ProfScope ps(ctx, "knn_redo");
-        SFM_HIP(ctx, launch_knn_redo(ctx->stream, ctx->jobs.as<KnnJob>(), 1, k));
+        SFM_HIP(ctx, launch_knn_redo(ctx->stream, ctx->jobs.as<KnnJob>(), 1, plan.n_splits, k));
     }
     if (!out_on_device) {
         SFM_HIP(ctx, hipMemcpyAsync(matches, out_dev, (size_t)nq * k * sizeof(sfm_gpu_dmatch),
@@ -431,6 +431,16 @@ int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* c, int variant)
 {
     if (!c) return SFM_GPU_ERR_ARG;
     c->knn_variant = variant;
+    return SFM_GPU_OK;
+}
+
+// Number of queries the last k-NN call on this context sent through the
+// exhaustive float-ranked pass (first job of the call).
+int sfm_gpu_debug_redo_count(sfm_gpu_ctx* ctx, int32_t* out)
+{
+    if (!ctx || !out || !ctx->redo.p) return SFM_GPU_ERR_ARG;
+    SFM_HIP(ctx, hipMemcpyAsync(out, ctx->redo.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SFM_GPU_OK;
 }
 

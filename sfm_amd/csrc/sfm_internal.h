@@ -101,7 +101,7 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
                        const KnnPlan& plan);
 hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_query_max,
                                int n_splits, int k);
-hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int k);
+hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_splits, int k);
 hipError_t launch_mfma_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c);
 
 }  // namespace sfm
