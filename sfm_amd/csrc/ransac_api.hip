@@ -54,7 +54,6 @@ size_t ransac_ws_bytes(int cap, int hyp_cap, int m)
     b += align_up((size_t)hyp_cap * 90 * 8, 256);        // models
     b += align_up((size_t)hyp_cap * 4, 256);             // nmodels
     b += align_up((size_t)hyp_cap * 10 * 4, 256);        // counts
-    b += 256;                                            // result
     b += align_up((size_t)cap, 256);                     // mask
     b += 256;                                            // model_out
     return b;
@@ -72,7 +71,6 @@ void carve_ransac(RansacProb& pb, char* base, int cap, int hyp_cap, int m)
     pb.models = (double*)take((size_t)hyp_cap * 90 * 8);
     pb.nmodels = (int32_t*)take((size_t)hyp_cap * 4);
     pb.counts = (int32_t*)take((size_t)hyp_cap * 10 * 4);
-    pb.result = (int32_t*)take(256);
     pb.mask = (uint8_t*)take((size_t)cap);
     pb.model_out = (double*)take(256);
 }
@@ -108,7 +106,8 @@ int fill_params(sfm_gpu_ctx* ctx, RansacProb& pb, const RansacParams& rp)
 // set) are in `probs`.  `results` receives n_prob * R_COUNT ints.  On return
 // the masks and models are on the device; the stream has been synchronised.
 int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int hyp_cap,
-                 const RansacParams& rp, const int32_t* custom_table_host, std::vector<int32_t>& results)
+                 const RansacParams& rp, const int32_t* custom_table_host, std::vector<int32_t>& results,
+                 bool need_results)
 {
     const int n_prob = (int)probs.size();
     const int m = probs[0].m;
@@ -121,10 +120,10 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         SFM_HIP(ctx, launch_ransac_prep(s, dprobs, n_prob, cap));
     }
     results.assign((size_t)n_prob * R_COUNT, 0);
+    // the result blocks of a batch are contiguous (probs[p].result = base + p * R_COUNT)
     auto fetch_results = [&]() -> int {
-        for (int p = 0; p < n_prob; ++p)
-            SFM_HIP(ctx, hipMemcpyAsync(&results[(size_t)p * R_COUNT], probs[p].result, R_COUNT * 4,
-                                        hipMemcpyDeviceToHost, s));
+        SFM_HIP(ctx, hipMemcpyAsync(results.data(), probs[0].result, (size_t)n_prob * R_COUNT * 4,
+                                    hipMemcpyDeviceToHost, s));
         SFM_HIP(ctx, hipStreamSynchronize(s));
         return SFM_GPU_OK;
     };
@@ -147,7 +146,7 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         }
         {
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, 0, nh));
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, rp.model, 0, nh));
         }
         {
             ProfScope ps(ctx, "ransac_select");
@@ -157,7 +156,9 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             ProfScope ps(ctx, "ransac_mask");
             SFM_HIP(ctx, launch_ransac_mask(s, dprobs, n_prob, cap));
         }
-        return fetch_results();
+        // the whole fixed-count path runs without the host; callers that keep
+        // working on the device need not wait here
+        return need_results ? fetch_results() : SFM_GPU_OK;
     }
 
     // Adaptive mode: hypotheses are scored in batches on the GPU and OpenCV's
@@ -195,7 +196,7 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         }
         {
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, done_rows, b));
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, rp.model, done_rows, b));
         }
         counts.resize((size_t)n_prob * b * 10);
         for (int p = 0; p < n_prob; ++p) {
@@ -253,8 +254,9 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         r[R_Q] = ok ? t.q : -1;
         r[R_NINL] = ok ? t.best : 0;
         r[R_ITERS] = t.iter;
-        SFM_HIP(ctx, hipMemcpyAsync(probs[p].result, r, 5 * 4, hipMemcpyHostToDevice, s));
     }
+    SFM_HIP(ctx, hipMemcpyAsync(probs[0].result, results.data(), (size_t)n_prob * R_COUNT * 4,
+                                hipMemcpyHostToDevice, s));
     {
         ProfScope ps(ctx, "ransac_mask");
         SFM_HIP(ctx, launch_ransac_mask(s, dprobs, n_prob, cap));
@@ -315,6 +317,8 @@ int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int
     probs[0].px2 = dpx2;
     probs[0].n_ptr = dn;
     carve_ransac(probs[0], ctx->rs_models.as<char>(), n, hyp_cap, m);
+    SFM_HIP(ctx, ctx->rs_counts.reserve(R_COUNT * 4));
+    probs[0].result = ctx->rs_counts.as<int32_t>();
     ctx->dbg_table = probs[0].table;
     ctx->dbg_counts = probs[0].counts;
     ctx->dbg_nmodels = probs[0].nmodels;
@@ -322,7 +326,7 @@ int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int
     ctx->dbg_hyp_cap = hyp_cap;
     ctx->dbg_m = m;
     std::vector<int32_t> results;
-    rc = ransac_batch(ctx, probs, n, hyp_cap, rp, (sample_table && n > m) ? sample_table : nullptr, results);
+    rc = ransac_batch(ctx, probs, n, hyp_cap, rp, (sample_table && n > m) ? sample_table : nullptr, results, true);
     if (rc) return rc;
     *ok = results[R_OK];
     if (iters_used) *iters_used = results[R_ITERS];
@@ -409,7 +413,8 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
     SFM_HIP(ctx, ctx->redo.reserve(redo_b * group));
     SFM_HIP(ctx, ctx->mp_good.reserve((good_b + inl_b) * group));
     SFM_HIP(ctx, ctx->mp_pts.reserve(px_b * 2 * group));
-    SFM_HIP(ctx, ctx->mp_ngood.reserve(256 * (size_t)group));
+    SFM_HIP(ctx, ctx->mp_ngood.reserve(8 * (size_t)group));
+    SFM_HIP(ctx, ctx->rs_counts.reserve((size_t)R_COUNT * 4 * group));
     SFM_HIP(ctx, ctx->rs_models.reserve(per_pair_ransac * group));
     SFM_HIP(ctx, ctx->jobs.reserve((sizeof(KnnJob) + sizeof(PairDev)) * (size_t)group));
 
@@ -441,7 +446,6 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
             j.n_train = t.n;
             j.q_rows_alloc = q.rows_alloc;
             j.t_chunks = t.n > 0 ? (t.n + CHUNK - 1) / CHUNK : 0;
-            SFM_HIP(ctx, hipMemsetAsync(j.redo, 0, 4, s));
             PairDev& pd = pds[i];
             pd.knn = j.out;
             pd.counts = j.counts;
@@ -451,7 +455,7 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
             pd.inliers = inlier_matches ? (sfm_gpu_dmatch*)((char*)pd.good + good_b) : nullptr;
             pd.px1 = (double*)(ctx->mp_pts.as<char>() + px_b * 2 * i);
             pd.px2 = (double*)(ctx->mp_pts.as<char>() + px_b * 2 * i + px_b);
-            pd.n_good = (int32_t*)(ctx->mp_ngood.as<char>() + 256 * (size_t)i);
+            pd.n_good = ctx->mp_ngood.as<int32_t>() + 2 * i;
             pd.n_inliers = pd.n_good + 1;
             pd.n_query = q.n;
             pd.capacity = match_capacity;
@@ -460,9 +464,12 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
             pb.px2 = pd.px2;
             pb.n_ptr = pd.n_good;
             carve_ransac(pb, ctx->rs_models.as<char>() + per_pair_ransac * i, nq_max, hyp_cap, m);
+            pb.result = ctx->rs_counts.as<int32_t>() + (size_t)R_COUNT * i;
             pd.mask = pb.mask;
             pd.result = pb.result;
         }
+        // one clear for all redo counters of the group (they head each job's list)
+        SFM_HIP(ctx, hipMemsetAsync(ctx->redo.p, 0, redo_b * g, s));
         KnnJob* djobs = ctx->jobs.as<KnnJob>();
         PairDev* dpds = (PairDev*)(ctx->jobs.as<char>() + sizeof(KnnJob) * (size_t)group);
         SFM_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), sizeof(KnnJob) * g, hipMemcpyHostToDevice, s));
@@ -483,14 +490,13 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
             ProfScope ps(ctx, "ratio_compact");
             SFM_HIP(ctx, launch_ratio_compact(s, dpds, g, params->ratio));
         }
-        rc = ransac_batch(ctx, probs, nq_max, hyp_cap, rp, nullptr, results);
+        rc = ransac_batch(ctx, probs, nq_max, hyp_cap, rp, nullptr, results, false);
         if (rc) return rc;
         {
             ProfScope ps(ctx, "inlier_compact");
             SFM_HIP(ctx, launch_inlier_compact(s, dpds, g));
         }
-        for (int i = 0; i < g; ++i)
-            SFM_HIP(ctx, hipMemcpyAsync(&ng[2 * i], pds[i].n_good, 8, hipMemcpyDeviceToHost, s));
+        SFM_HIP(ctx, hipMemcpyAsync(ng.data(), ctx->mp_ngood.p, 8 * (size_t)g, hipMemcpyDeviceToHost, s));
         SFM_HIP(ctx, hipStreamSynchronize(s));
         for (int i = 0; i < g; ++i) {
             n_good[g0 + i] = ng[2 * i];

@@ -49,7 +49,7 @@ hipError_t launch_ransac_prep(hipStream_t s, const RansacProb* probs, int n_prob
 hipError_t launch_ransac_table(hipStream_t s, const RansacProb* probs, int n_prob, int row0, int nrows);
 hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int n_prob, int nrows);
 hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int hyp0, int n_hyp);
-hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int hyp0, int n_hyp);
+hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp);
 hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp);
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
 

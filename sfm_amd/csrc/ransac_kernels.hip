@@ -570,19 +570,30 @@ __device__ __forceinline__ int sampson_inlier(const double* E, double u1, double
     return (float)(s2 / den) <= tf ? 1 : 0;
 }
 
-__device__ __forceinline__ int symepi_inlier(const double* F, float fx1, float fy1, float fx2, float fy2, float tf)
+// Symmetric epipolar test: (float)max(d1^2/den1, d2^2/den2) <= tf, evaluated as
+// OpenCV does (reciprocal, then two multiplies) only when the outcome is not
+// already certain from den*t comparisons with 2^-20 relative margins.
+__device__ __forceinline__ int symepi_inlier(const double* F, float fx1, float fy1, float fx2, float fy2,
+                                             float tf, double tlo, double thi)
 {
     const double x1 = fx1, y1 = fy1, x2 = fx2, y2 = fy2;
     double a = (F[0] * x1 + F[1] * y1) + F[2];
     double b = (F[3] * x1 + F[4] * y1) + F[5];
     double c = (F[6] * x1 + F[7] * y1) + F[8];
-    const double s2 = 1. / (a * a + b * b);
+    const double den2 = a * a + b * b;
     const double d2 = (x2 * a + y2 * b) + c;
     a = (F[0] * x2 + F[3] * y2) + F[6];
     b = (F[1] * x2 + F[4] * y2) + F[7];
     c = (F[2] * x2 + F[5] * y2) + F[8];
-    const double s1 = 1. / (a * a + b * b);
+    const double den1 = a * a + b * b;
     const double d1 = (x1 * a + y1 * b) + c;
+    const double n1 = d1 * d1, n2 = d2 * d2;
+    if (den1 > 0.0 && den1 <= DBL_MAX && den2 > 0.0 && den2 <= DBL_MAX) {
+        if (n1 >= den1 * thi || n2 >= den2 * thi) return 0;
+        if (n1 <= den1 * tlo && n2 <= den2 * tlo) return 1;
+    }
+    const double s2 = 1. / den2;
+    const double s1 = 1. / den1;
     return (float)fmax(d1 * d1 * s1, d2 * d2 * s2) <= tf ? 1 : 0;
 }
 
@@ -808,57 +819,84 @@ __global__ void __launch_bounds__(64) ransac_solve_kernel(const RansacProb* __re
     if (lane == 0) pb.nmodels[hyp] = nm;
 }
 
-// Inlier counts of every candidate model of one hypothesis over all points.
-__global__ void __launch_bounds__(256) ransac_score_kernel(const RansacProb* __restrict__ probs, int hyp0)
+// Inlier counts of every candidate model of H consecutive hypotheses over all
+// points: each thread loads a point once and tests it against all their models.
+template <int MODEL, int MAXM, int H>
+__global__ void __launch_bounds__(256)
+ransac_score_kernel(const RansacProb* __restrict__ probs, int hyp0, int n_hyp)
 {
-    __shared__ double sE[10][9];
-    __shared__ int sCnt[10];
+    __shared__ double sM[H * MAXM][9];
+    __shared__ int sNm[H];
+    __shared__ int sCnt[H * MAXM];
     const RansacProb pb = probs[blockIdx.y];
-    const int hyp = hyp0 + blockIdx.x;
+    const int hypb = hyp0 + blockIdx.x * H;
     const int n = *pb.n_ptr;
     const int tid = threadIdx.x;
-    int nm = 0;
-    if (n >= pb.m && hyp < pb.result[R_VALID]) nm = pb.nmodels[hyp];
-    if (nm == 0) {
-        if (tid < 10) pb.counts[(size_t)hyp * 10 + tid] = -1;
-        return;
+    if (tid < H) {
+        const int hyp = hypb + tid;
+        int nm = 0;
+        if (hyp < hyp0 + n_hyp && n >= pb.m && hyp < pb.result[R_VALID]) nm = min(pb.nmodels[hyp], MAXM);
+        sNm[tid] = nm;
     }
-    if (tid < nm * 9) sE[tid / 9][tid % 9] = pb.models[(size_t)hyp * 90 + tid];
-    if (tid < 10) sCnt[tid] = 0;
+    if (tid < H * MAXM) sCnt[tid] = 0;
     __syncthreads();
-    int cnt[10];
-#pragma unroll
-    for (int q = 0; q < 10; ++q) cnt[q] = 0;
-    if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
-        const double2* X1 = (const double2*)pb.x1;
-        const double2* X2 = (const double2*)pb.x2;
-        for (int i = tid; i < n; i += 256) {
-            const double2 a = X1[i], b = X2[i];
-#pragma unroll
-            for (int q = 0; q < 10; ++q)
-                if (q < nm) cnt[q] += sampson_inlier(sE[q], a.x, a.y, b.x, b.y, pb.tf, pb.tlo, pb.thi);
-        }
-    } else {
-        const float2* X1 = (const float2*)pb.f1;
-        const float2* X2 = (const float2*)pb.f2;
-        for (int i = tid; i < n; i += 256) {
-            const float2 a = X1[i], b = X2[i];
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                if (q < nm) cnt[q] += symepi_inlier(sE[q], a.x, a.y, b.x, b.y, pb.tf);
-        }
+    for (int idx = tid; idx < H * MAXM * 9; idx += 256) {
+        const int hh = idx / (MAXM * 9), r = idx - hh * (MAXM * 9);
+        if (r < sNm[hh] * 9) sM[hh * MAXM + r / 9][r % 9] = pb.models[(size_t)(hypb + hh) * 90 + r];
     }
+    int nmv[H];
+    int total = 0;
 #pragma unroll
-    for (int q = 0; q < 10; ++q) {
-        if (q < nm) {
-            int v = cnt[q];
+    for (int hh = 0; hh < H; ++hh) {
+        nmv[hh] = sNm[hh];
+        total += nmv[hh];
+    }
+    __syncthreads();
+    int cnt[H * MAXM];
+#pragma unroll
+    for (int c = 0; c < H * MAXM; ++c) cnt[c] = 0;
+    if (total > 0) {
+        if (MODEL == SFM_GPU_MODEL_ESSENTIAL) {
+            const double2* X1 = (const double2*)pb.x1;
+            const double2* X2 = (const double2*)pb.x2;
+            for (int i = tid; i < n; i += 256) {
+                const double2 a = X1[i], b = X2[i];
+#pragma unroll
+                for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+                    for (int q = 0; q < MAXM; ++q)
+                        if (q < nmv[hh])
+                            cnt[hh * MAXM + q] +=
+                                sampson_inlier(sM[hh * MAXM + q], a.x, a.y, b.x, b.y, pb.tf, pb.tlo, pb.thi);
+            }
+        } else {
+            const float2* X1 = (const float2*)pb.f1;
+            const float2* X2 = (const float2*)pb.f2;
+            for (int i = tid; i < n; i += 256) {
+                const float2 a = X1[i], b = X2[i];
+#pragma unroll
+                for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+                    for (int q = 0; q < MAXM; ++q)
+                        if (q < nmv[hh])
+                            cnt[hh * MAXM + q] +=
+                                symepi_inlier(sM[hh * MAXM + q], a.x, a.y, b.x, b.y, pb.tf, pb.tlo, pb.thi);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < H * MAXM; ++c) {
+            int v = cnt[c];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if ((tid & 63) == 0) atomicAdd(&sCnt[q], v);
+            if ((tid & 63) == 0 && v != 0) atomicAdd(&sCnt[c], v);
         }
     }
     __syncthreads();
-    if (tid < 10) pb.counts[(size_t)hyp * 10 + tid] = tid < nm ? sCnt[tid] : -1;
+    if (tid < H * 10) {
+        const int hh = tid / 10, q = tid - hh * 10;
+        const int hyp = hypb + hh;
+        if (hyp < hyp0 + n_hyp) pb.counts[(size_t)hyp * 10 + q] = q < sNm[hh] ? sCnt[hh * MAXM + q] : -1;
+    }
 }
 
 // Fixed-count winner: the first (hypothesis, model) in scan order whose count is
@@ -929,7 +967,7 @@ __global__ void __launch_bounds__(256) ransac_mask_kernel(const RansacProb* __re
         f = sampson_inlier(M, pb.x1[2 * i], pb.x1[2 * i + 1], pb.x2[2 * i], pb.x2[2 * i + 1], pb.tf,
                            pb.tlo, pb.thi);
     } else {
-        f = symepi_inlier(M, pb.f1[2 * i], pb.f1[2 * i + 1], pb.f2[2 * i], pb.f2[2 * i + 1], pb.tf);
+        f = symepi_inlier(M, pb.f1[2 * i], pb.f1[2 * i + 1], pb.f2[2 * i], pb.f2[2 * i + 1], pb.tf, pb.tlo, pb.thi);
     }
     pb.mask[i] = (uint8_t)f;
 }
@@ -957,9 +995,17 @@ hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_pro
     hipLaunchKernelGGL(ransac_solve_kernel, dim3(n_hyp, n_prob), dim3(64), 0, s, probs, hyp0);
     return hipGetLastError();
 }
-hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int hyp0, int n_hyp)
+hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp)
 {
-    hipLaunchKernelGGL(ransac_score_kernel, dim3(n_hyp, n_prob), dim3(256), 0, s, probs, hyp0);
+    if (model == SFM_GPU_MODEL_ESSENTIAL) {
+        constexpr int H = 1;
+        hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL, 10, H>), dim3((n_hyp + H - 1) / H, n_prob),
+                           dim3(256), 0, s, probs, hyp0, n_hyp);
+    } else {
+        constexpr int H = 1;
+        hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL, 3, H>), dim3((n_hyp + H - 1) / H, n_prob),
+                           dim3(256), 0, s, probs, hyp0, n_hyp);
+    }
     return hipGetLastError();
 }
 hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp)
