@@ -114,50 +114,96 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Workgroup id -> (query block, train part, job).  Consecutive workgroup ids
+// are dealt to the 8 XCDs round-robin and each XCD has its own L2, so the
+// workgroups that stream the same train rows are given ids that are equal
+// modulo 8 whenever the launch allows it:
+//   mode 1 (jobs % 8 == 0)    all workgroups of a job run on one XCD
+//   mode 2 (parts % 8 == 0)   all workgroups of a train part run on one XCD
+//   mode 0                    plain order
+struct WgCoord {
+    int qblock, split, job;
+};
+__device__ __forceinline__ WgCoord decode_wg(uint32_t id, uint32_t qblocks, uint32_t splits, int mode)
+{
+    WgCoord c;
+    if (mode == 1) {
+        const uint32_t per_job = qblocks * splits;
+        const uint32_t j = id >> 3;
+        const uint32_t w = j % per_job;
+        c.job = (int)((j / per_job) * 8 + (id & 7));
+        c.qblock = (int)(w % qblocks);
+        c.split = (int)(w / qblocks);
+    } else if (mode == 2) {
+        const uint32_t r = id / splits;
+        c.split = (int)(id % splits);
+        c.qblock = (int)(r % qblocks);
+        c.job = (int)(r / qblocks);
+    } else {
+        const uint32_t r = id / qblocks;
+        c.qblock = (int)(id % qblocks);
+        c.split = (int)(r % splits);
+        c.job = (int)(r / splits);
+    }
+    return c;
+}
+
+#define SFM_SB() __builtin_amdgcn_sched_barrier(0)
+
 // Distance sweep.  Workgroup = WAVES waves, each owning QB blocks of 32
-// queries; blockIdx.y selects a contiguous part of the train rows (a sweep of
-// at most 512 tiles), blockIdx.z the job.
+// queries whose fragments stay in registers; the workgroup streams one part of
+// the train rows (at most 512 tiles of 32 rows) through LDS in stages of ST
+// rows, three buffers deep.
 //
 // Per 32x32 tile the accumulators of one lane are x for ONE query against 16
 // train rows (a "group": rows 8g+4h+i of the tile, g,i = 0..3).  The lane keeps
 // the three smallest group minima seen so far, the best two tagged with their
-// tile: 8 min3 + 1 pack + 5 min/max/med3 per tile, no branch, no cross-lane
-// traffic.  The exact neighbours are then picked by knn_rescan_kernel among
-// the rows of the two best groups of each query.
-template <int QB, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
-knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int ablate)
+// tile: 8 min/min3 + 1 pack + 4 min/max/med3 per tile and query block, no
+// branch, no cross-lane traffic.  The exact neighbours are then picked by
+// knn_rescan_kernel among the rows of the two best groups of each query.
+//
+// Schedule.  A "unit" is one train tile against one query block: 4 chained
+// MFMAs.  The instruction stream is pinned (sched_barrier after every group):
+// each MFMA of unit u is followed by a share of the 13 VALU operations that
+// digest the accumulators of unit u-1 and by the LDS reads of the next tile's
+// fragments, so the matrix pipe always has the next MFMA queued behind the one
+// executing.  The stage hand-over needs one barrier per stage, placed inside
+// the stream (after the first unit) where no wave has to wait for data: at that
+// point every wave has finished reading stage s-1, stage s+1 landed long ago,
+// and the DMA of stage s+2 may overwrite the buffer of stage s-1.
+template <int QB, int WAVES, int ABLATE>
+__global__ void __launch_bounds__(WAVES * 64, 8 / WAVES)  // two waves per SIMD: accumulators stay in VGPRs
+knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblocks, int splits,
+                 int map_mode)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * LDS_STAGE];
+    static_assert(QB == 1 || QB == 2 || QB == 4 || QB == 8, "QB must divide 8");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * LDS_STAGE];
 
-    const KnnJob job = jobs[blockIdx.z];
+    const WgCoord wg = decode_wg(blockIdx.x, (uint32_t)qblocks, (uint32_t)splits, map_mode);
+    const KnnJob job = jobs[wg.job];
     constexpr int QPB = WAVES * QB * 32;
-    if ((int)blockIdx.x * QPB >= job.n_query) return;
-    const int c0 = blockIdx.y * chunks_per_split;
+    if (wg.qblock * QPB >= job.n_query) return;
+    const int c0 = wg.split * chunks_per_split;
     const int c1 = min(c0 + chunks_per_split, job.t_chunks);
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int col = lane & 31;  // query within a block of 32 (MFMA column)
     const int h = lane >> 5;    // which half of the K bytes / which row quartets
-    const int q_base = (blockIdx.x * WAVES + wave) * (QB * 32);
+    const int q_base = (wg.qblock * WAVES + wave) * (QB * 32);
 
-    // Query fragments stay in registers for the whole sweep: lane (col, h)
-    // holds bytes [64h, 64h+64) of its query row, complemented.
+    // Query fragments: lane (col, h) holds bytes [64h, 64h+64) of its query
+    // row, complemented.
     v4i bq[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const v4i* qp = (const v4i*)(job.q_desc + (size_t)(q_base + qb * 32 + col) * DIM + 64 * h);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bq[qb][s] = ~qp[s];
+        for (int k = 0; k < 4; ++k) bq[qb][k] = ~qp[k];
     }
-    // per-query-block state as register vectors (constant indices only)
-    typedef uint32_t uQ __attribute__((ext_vector_type(QB)));
-    uQ m1, m2, m3;
-    static_for<QB>([&](auto qbc) {
-        constexpr int qb = decltype(qbc)::value;
-        m1[qb] = m2[qb] = m3[qb] = 0xFFFFFFFFu;
-    });
+    uint32_t m1[QB], m2[QB], m3[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) m1[qb] = m2[qb] = m3[qb] = 0xFFFFFFFFu;
 
     // Stage image in LDS: row-major 128-B rows of eight 16-B slots, slot cs of
     // row r holding source chunk cs ^ ((r >> 1) & 7), which makes the
@@ -166,8 +212,8 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int abla
     // wave-instruction moves 8 rows.
     const int dma_r = lane >> 3;
     const int dma_cs = lane & 7;
-    auto issue_stage = [&](int buf, int row0) {
-        unsigned char* dst = lds + buf * LDS_STAGE;
+    auto issue_stage = [&](int bufi, int row0) {
+        unsigned char* dst = lds + bufi * LDS_STAGE;
 #pragma unroll
         for (int k = wave; k < ST / 8; k += WAVES) {
             const int r = 8 * k + dma_r;
@@ -177,83 +223,151 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int abla
         if (wave == WAVES - 1 && lane < ST / 4) glds16(job.t_cin + row0 + lane * 4, dst + LDS_DESC);
     };
 
-    struct Frag {
-        v4i a[4];
-        v4i c[4];
-    };
-    auto load_frag = [&](Frag& f, const unsigned char* buf, int tile) {
-        const int r = tile * 32 + col;
-        const int swz = (r >> 1) & 7;
+    // Fragment addresses inside a stage buffer.  The swizzle term of row
+    // 32*tile + col does not depend on the tile.
+    const int swz = (col >> 1) & 7;
+    int a_off[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) f.a[k] = *(const v4i*)(buf + (r * 8 + ((4 * h + k) ^ swz)) * 16);
-        // accumulator register 4g+i of this lane is train row 8g + 4h + i
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            f.c[g] = *(const v4i*)(buf + LDS_DESC + (tile * 32 + 8 * g + 4 * h) * 4);
-    };
-    auto compute_tile = [&](const Frag& f, uint32_t tile_id) {
-        v16i cinv;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            cinv[4 * g + 0] = f.c[g][0];
-            cinv[4 * g + 1] = f.c[g][1];
-            cinv[4 * g + 2] = f.c[g][2];
-            cinv[4 * g + 3] = f.c[g][3];
-        }
-        static_for<QB>([&](auto qbc) {
-            constexpr int qb = decltype(qbc)::value;
-            v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[0], bq[qb][0], cinv, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[1], bq[qb][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[2], bq[qb][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[3], bq[qb][3], acc, 0, 0, 0);
-            if (ablate == 2) {  // timing experiment: MFMA only (wrong results)
-                asm volatile("" ::"v"(acc));
-                return;
-            }
-            uint32_t t = umin32(umin32((uint32_t)acc[0], (uint32_t)acc[1]), (uint32_t)acc[2]);
-#pragma unroll
-            for (int i = 3; i < 15; i += 2)
-                t = umin32(umin32(t, (uint32_t)acc[i]), (uint32_t)acc[i + 1]);
-            t = umin32(t, (uint32_t)acc[15]);
-            const uint32_t p = (t << TILE_BITS) | tile_id;
-            const uint32_t n3 = umin32(m3[qb], umax32(m2[qb], p));
-            const uint32_t n2 = umed3(m1[qb], m2[qb], p);
-            m1[qb] = umin32(m1[qb], p);
-            m2[qb] = n2;
-            m3[qb] = n3;
-        });
-    };
+    for (int k = 0; k < 4; ++k) a_off[k] = col * DIM + (((4 * h + k) ^ swz) << 4);
+    // accumulator register 4g+i of this lane is train row 8g + 4h + i
+    const int c_off = LDS_DESC + 16 * h;
+
+    v4i fa[2][4];  // train fragments of the current / next tile
+    v16i fc[2];    // their cin values in accumulator layout
+    v16i acc[2];   // accumulators of the current / previous unit
+    constexpr int U = (ST / 32) * QB;  // units per stage
+    constexpr int PARTS = 8 / QB;      // LDS reads issued per unit
 
     const int n_stage = (c1 - c0) * (CHUNK / ST);
-    if (n_stage > 0) issue_stage(0, c0 * CHUNK);
-    for (int s = 0; s < n_stage; ++s) {
-        // Hand-placed wait + raw barrier (the compiler does not order LDS-DMA by
-        // itself): this wave's DMA of stage s has landed (vmcnt), then everyone's
-        // has (barrier), and every wave is done reading the buffer that stage
-        // s+1 is about to overwrite.
+    const int row_base = c0 * CHUNK;
+
+    // digest of a finished unit: three smallest group minima per query block
+    auto minima_lo = [&](const v16i& a) -> uint32_t {
+        uint32_t t = umin32((uint32_t)a[0], (uint32_t)a[1]);
+        t = umin32(umin32(t, (uint32_t)a[2]), (uint32_t)a[3]);
+        t = umin32(umin32(t, (uint32_t)a[4]), (uint32_t)a[5]);
+        t = umin32(umin32(t, (uint32_t)a[6]), (uint32_t)a[7]);
+        t = umin32(umin32(t, (uint32_t)a[8]), (uint32_t)a[9]);
+        return t;
+    };
+    auto minima_hi = [&](uint32_t t, const v16i& a) -> uint32_t {
+        t = umin32(umin32(t, (uint32_t)a[10]), (uint32_t)a[11]);
+        t = umin32(umin32(t, (uint32_t)a[12]), (uint32_t)a[13]);
+        t = umin32(umin32(t, (uint32_t)a[14]), (uint32_t)a[15]);
+        return t;
+    };
+
+    if (n_stage > 0) {
+        issue_stage(0, row_base);
+        if (n_stage > 1) issue_stage(1, row_base + ST);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < n_stage) issue_stage((s + 1) & 1, c0 * CHUNK + (s + 1) * ST);
-        const unsigned char* buf = lds + (s & 1) * LDS_STAGE;
-        const uint32_t tile0 = (uint32_t)s * (ST / 32);
-        Frag f0, f1;
-        load_frag(f0, buf, 0);
-        load_frag(f1, buf, 1);
-        compute_tile(f0, tile0 + 0);
-        load_frag(f0, buf, 2);
-        compute_tile(f1, tile0 + 1);
-        load_frag(f1, buf, 3);
-        compute_tile(f0, tile0 + 2);
-        compute_tile(f1, tile0 + 3);
+        SFM_SB();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fa[0][k] = *(const v4i*)(lds + a_off[k]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const v4i c = *(const v4i*)(lds + c_off + g * 32);
+            fc[0][4 * g + 0] = c[0];
+            fc[0][4 * g + 1] = c[1];
+            fc[0][4 * g + 2] = c[2];
+            fc[0][4 * g + 3] = c[3];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[1][i] = 0;
+
+        int cur = 0;
+        uint32_t first = 0xFFFFFFFFu;  // masks the digest of the unit before the first one
+        for (int s = 0; s < n_stage; ++s) {
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            const int nx2 = nxt == 2 ? 0 : nxt + 1;
+            const unsigned char* buf = lds + cur * LDS_STAGE;
+            const unsigned char* nbuf = lds + nxt * LDS_STAGE;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = u / QB, qb = u % QB, set = t & 1, nset = set ^ 1;
+                const int pqb = (u + U - 1) % U % QB;
+                // tile of the previous unit within the sweep
+                const uint32_t ptile = (uint32_t)(s * (ST / 32) + (u == 0 ? -1 : (u - 1) / QB));
+                const v16i& pa = acc[(u + 1) & 1];
+                // next tile's fragments: next tile of this stage, or tile 0 of the
+                // next stage (a stale buffer after the last stage: never used)
+                const unsigned char* nd = t < ST / 32 - 1 ? buf + (t + 1) * 32 * DIM : nbuf;
+                const unsigned char* nc = t < ST / 32 - 1 ? buf + (t + 1) * 32 * 4 : nbuf;
+                uint32_t tmin = 0, p = 0;
+
+                acc[u & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][0], bq[qb][0], fc[set], 0, 0, 0);
+                SFM_SB();
+#pragma unroll
+                for (int part = qb * PARTS; part < (qb + 1) * PARTS; ++part) {
+                    if (part < 4) {
+                        fa[nset][part] = *(const v4i*)(nd + a_off[part]);
+                    } else {
+                        const v4i c = *(const v4i*)(nc + c_off + (part - 4) * 32);
+                        fc[nset][4 * (part - 4) + 0] = c[0];
+                        fc[nset][4 * (part - 4) + 1] = c[1];
+                        fc[nset][4 * (part - 4) + 2] = c[2];
+                        fc[nset][4 * (part - 4) + 3] = c[3];
+                    }
+                }
+                if (u == 1) {
+                    // stage s+1 has landed (this wave's share, then everyone's), and
+                    // every wave is past its last read of stage s-1
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    SFM_SB();
+                    if (s + 2 < n_stage) issue_stage(nx2, row_base + (s + 2) * ST);
+                }
+                SFM_SB();
+                acc[u & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][1], bq[qb][1], acc[u & 1], 0, 0, 0);
+                SFM_SB();
+                if (ABLATE != 2) tmin = minima_lo(pa);
+                SFM_SB();
+                acc[u & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][2], bq[qb][2], acc[u & 1], 0, 0, 0);
+                SFM_SB();
+                if (ABLATE != 2) {
+                    tmin = minima_hi(tmin, pa);
+                    p = (tmin << TILE_BITS) | ptile;
+                    if (u == 0) p |= first;
+                }
+                SFM_SB();
+                acc[u & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][3], bq[qb][3], acc[u & 1], 0, 0, 0);
+                SFM_SB();
+                if (ABLATE != 2) {
+                    const uint32_t n3 = umin32(m3[pqb], umax32(m2[pqb], p));
+                    const uint32_t n2 = umed3(m1[pqb], m2[pqb], p);
+                    m1[pqb] = umin32(m1[pqb], p);
+                    m2[pqb] = n2;
+                    m3[pqb] = n3;
+                } else {
+                    asm volatile("" ::"v"(pa));
+                }
+                SFM_SB();
+            }
+            first = 0;
+            cur = nxt;
+        }
+        // digest of the very last unit
+        if (ABLATE != 2) {
+            const v16i& pa = acc[(U - 1) & 1];
+            const uint32_t tmin = minima_hi(minima_lo(pa), pa);
+            const uint32_t p = (tmin << TILE_BITS) | (uint32_t)(n_stage * (ST / 32) - 1);
+            const uint32_t n3 = umin32(m3[QB - 1], umax32(m2[QB - 1], p));
+            const uint32_t n2 = umed3(m1[QB - 1], m2[QB - 1], p);
+            m1[QB - 1] = umin32(m1[QB - 1], p);
+            m2[QB - 1] = n2;
+            m3[QB - 1] = n3;
+        } else {
+            asm volatile("" ::"v"(acc[(U - 1) & 1]));
+        }
     }
 
     // Lanes l and l+32 hold the same query over disjoint groups: merge their
     // triples; lane l < 32 writes one record per (split, query):
     //   x = best group (x << 9 | tile), y = second group, z = third minimum,
     //   w = first tile of the sweep | half of best << 30 | half of second << 31
-    static_for<QB>([&](auto qbc) {
-        constexpr int qb = decltype(qbc)::value;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
         typedef unsigned long long u64;
         const u64 NONE = ~0ull;
         auto key = [&](uint32_t p, int hh) -> u64 {
@@ -262,27 +376,27 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int abla
         const uint32_t o1 = (uint32_t)__shfl_xor((int)m1[qb], 32);
         const uint32_t o2 = (uint32_t)__shfl_xor((int)m2[qb], 32);
         const uint32_t o3 = (uint32_t)__shfl_xor((int)m3[qb], 32);
-        u64 c1 = key(m1[qb], h), c2 = key(m2[qb], h), c3 = key(m3[qb], h);
+        u64 k1 = key(m1[qb], h), k2 = key(m2[qb], h), k3 = key(m3[qb], h);
         const u64 b[3] = {key(o1, h ^ 1), key(o2, h ^ 1), key(o3, h ^ 1)};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const u64 v = b[j];
-            if (v < c3) {
-                c3 = v;
-                if (c3 < c2) { const u64 t = c2; c2 = c3; c3 = t; }
-                if (c2 < c1) { const u64 t = c1; c1 = c2; c2 = t; }
+            if (v < k3) {
+                k3 = v;
+                if (k3 < k2) { const u64 t = k2; k2 = k3; k3 = t; }
+                if (k2 < k1) { const u64 t = k1; k1 = k2; k2 = t; }
             }
         }
         if (h == 0) {
             const int q = q_base + qb * 32 + col;
             uint4 o;
-            o.x = c1 == NONE ? 0xFFFFFFFFu : (uint32_t)(c1 >> 1);
-            o.y = c2 == NONE ? 0xFFFFFFFFu : (uint32_t)(c2 >> 1);
-            o.z = c3 == NONE ? 0xFFFFFFFFu : (uint32_t)(c3 >> 1);
-            o.w = (uint32_t)(c0 * (CHUNK / 32)) | ((uint32_t)(c1 & 1) << 30) | ((uint32_t)(c2 & 1) << 31);
-            job.partial[(size_t)blockIdx.y * job.q_rows_alloc + q] = o;
+            o.x = k1 == NONE ? 0xFFFFFFFFu : (uint32_t)(k1 >> 1);
+            o.y = k2 == NONE ? 0xFFFFFFFFu : (uint32_t)(k2 >> 1);
+            o.z = k3 == NONE ? 0xFFFFFFFFu : (uint32_t)(k3 >> 1);
+            o.w = (uint32_t)(c0 * (CHUNK / 32)) | ((uint32_t)(k1 & 1) << 30) | ((uint32_t)(k2 & 1) << 31);
+            job.partial[(size_t)wg.split * job.q_rows_alloc + q] = o;
         }
-    });
+    }
 }
 
 // ---------------------------------------------------------------- rescan ----
@@ -635,7 +749,9 @@ KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant
     // never more than MAX_SWEEP_CHUNKS chunks per part.
     int splits = (t_chunks + MAX_SWEEP_CHUNKS - 1) / MAX_SWEEP_CHUNKS;
     if (splits < 1) splits = 1;
-    while (qblocks * splits < 256 && splits * 2 <= t_chunks && t_chunks / (splits * 2) >= 2)
+    // two resident workgroups per CU for the 4-wave shapes, one for the 8-wave ones
+    const long long want = (p.variant == 0 || p.variant == 1) ? 512 : 256;
+    while (qblocks * splits < want && splits * 2 <= t_chunks && t_chunks / (splits * 2) >= 2)
         splits *= 2;
     p.n_splits = splits;
     p.chunks_per_split = (t_chunks + splits - 1) / splits;
@@ -648,25 +764,25 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
                        const KnnPlan& plan)
 {
     const int qblocks = (q_rows_alloc_max + plan.q_per_block - 1) / plan.q_per_block;
-    const dim3 grid(qblocks, plan.n_splits, n_jobs);
+    const int splits = plan.n_splits;
+    const long long total = (long long)qblocks * splits * n_jobs;
+    if (total <= 0) return hipSuccess;
+    if (total > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    const int mode = (n_jobs % 8 == 0) ? 1 : (splits % 8 == 0) ? 2 : 0;
+    const dim3 grid((unsigned)total);
+#define SFM_KNN2(QB, WAVES, ABL)                                                                  \
+    hipLaunchKernelGGL((knn2_mfma_kernel<QB, WAVES, ABL>), grid, dim3(WAVES * 64), 0, s, jobs_dev, \
+                       plan.chunks_per_split, qblocks, splits, mode)
     switch (plan.variant) {
-        case 1:
-            hipLaunchKernelGGL((knn2_mfma_kernel<2, 4>), grid, dim3(256), 0, s, jobs_dev,
-                               plan.chunks_per_split, plan.ablate);
-            break;
-        case 2:
-            hipLaunchKernelGGL((knn2_mfma_kernel<2, 8>), grid, dim3(512), 0, s, jobs_dev,
-                               plan.chunks_per_split, plan.ablate);
-            break;
-        case 3:
-            hipLaunchKernelGGL((knn2_mfma_kernel<4, 8>), grid, dim3(512), 0, s, jobs_dev,
-                               plan.chunks_per_split, plan.ablate);
-            break;
+        case 1: SFM_KNN2(2, 4, 0); break;
+        case 2: SFM_KNN2(2, 8, 0); break;
+        case 3: SFM_KNN2(4, 8, 0); break;
         default:
-            hipLaunchKernelGGL((knn2_mfma_kernel<4, 4>), grid, dim3(256), 0, s, jobs_dev,
-                               plan.chunks_per_split, plan.ablate);
+            if (plan.ablate == 2) SFM_KNN2(4, 4, 2);
+            else SFM_KNN2(4, 4, 0);
             break;
     }
+#undef SFM_KNN2
     return hipGetLastError();
 }
 

@@ -54,6 +54,7 @@ size_t ransac_ws_bytes(int cap, int hyp_cap, int m)
     b += align_up((size_t)hyp_cap * 90 * 8, 256);        // models
     b += align_up((size_t)hyp_cap * 4, 256);             // nmodels
     b += align_up((size_t)hyp_cap * 10 * 4, 256);        // counts
+    b += align_up((size_t)hyp_cap * 10 * 4, 256);        // list
     b += align_up((size_t)cap, 256);                     // mask
     b += 256;                                            // model_out
     return b;
@@ -71,6 +72,7 @@ void carve_ransac(RansacProb& pb, char* base, int cap, int hyp_cap, int m)
     pb.models = (double*)take((size_t)hyp_cap * 90 * 8);
     pb.nmodels = (int32_t*)take((size_t)hyp_cap * 4);
     pb.counts = (int32_t*)take((size_t)hyp_cap * 10 * 4);
+    pb.list = (int32_t*)take((size_t)hyp_cap * 10 * 4);
     pb.mask = (uint8_t*)take((size_t)cap);
     pb.model_out = (double*)take(256);
 }
@@ -142,11 +144,11 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         }
         {
             ProfScope ps(ctx, "ransac_solve");
-            SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, 0, nh));
+            SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, rp.model, 0, nh));
         }
         {
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, rp.model, 0, nh));
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh));
         }
         {
             ProfScope ps(ctx, "ransac_select");
@@ -192,11 +194,11 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         }
         {
             ProfScope ps(ctx, "ransac_solve");
-            SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, done_rows, b));
+            SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, rp.model, done_rows, b));
         }
         {
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, rp.model, done_rows, b));
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, done_rows, b));
         }
         counts.resize((size_t)n_prob * b * 10);
         for (int p = 0; p < n_prob; ++p) {

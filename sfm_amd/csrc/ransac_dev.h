@@ -18,6 +18,7 @@ enum {
     R_RNG_HI = 7,  // generator state parked between table batches
     R_RNG_LO = 8,
     R_N = 9,       // copy of the point count
+    R_NLIST = 10,  // candidate models listed for the batch being scored
     R_COUNT = 16
 };
 
@@ -27,7 +28,7 @@ struct RansacProb {
     const double* px1;     // [n][2] pixel coordinates, image 1
     const double* px2;     // [n][2] pixel coordinates, image 2
     const int32_t* n_ptr;  // device: number of correspondences
-    double* x1;            // [cap][2] normalised (essential model)
+    double* x1;            // [cap][2] normalised (essential model) / float32 pixels widened (fundamental)
     double* x2;
     float* f1;             // [cap][2] float32 pixels (fundamental model)
     float* f2;
@@ -35,6 +36,7 @@ struct RansacProb {
     double* models;        // [hyp_cap][MAX_MODELS][9]
     int32_t* nmodels;      // [hyp_cap]
     int32_t* counts;       // [hyp_cap][MAX_MODELS], -1 = no such model
+    int32_t* list;         // [hyp_cap * MAX_MODELS] dense list of hyp*MAX_MODELS + q of one batch
     int32_t* result;       // [R_COUNT]
     uint8_t* mask;         // [cap]
     double* model_out;     // [9]
@@ -48,8 +50,9 @@ struct RansacProb {
 hipError_t launch_ransac_prep(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
 hipError_t launch_ransac_table(hipStream_t s, const RansacProb* probs, int n_prob, int row0, int nrows);
 hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int n_prob, int nrows);
-hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int hyp0, int n_hyp);
-hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp);
+hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp);
+hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
+                               int n_hyp);
 hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp);
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
 

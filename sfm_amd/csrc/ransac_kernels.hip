@@ -543,6 +543,298 @@ __device__ int seven_point_wave(SolveWs& w, const float* m1, const float* m2, do
     return nr;
 }
 
+
+// ---- seven-point solver, one THREAD per hypothesis -----------------------------
+// The seven-point algorithm is short and almost entirely sequential, so 64
+// hypotheses share a wavefront, each lane running the sequential statement of
+// the algorithm.  The 7x9 system lives in LDS as element-major columns
+// (element e of lane l at sA[e*64 + l]): any per-lane choice of pivot row or
+// column then hits the lane's own bank pair, so the dynamically indexed swaps
+// of complete pivoting are conflict-free.
+
+template <int NA, int NB>
+__device__ __forceinline__ void pmul_t(const double* a, const double* b, double* out)
+{
+#pragma unroll
+    for (int i = 0; i <= NA + NB; ++i) out[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i <= NA; ++i)
+#pragma unroll
+        for (int j = 0; j <= NB; ++j) out[i + j] = out[i + j] + a[i] * b[j];
+}
+
+template <int N>
+__device__ __forceinline__ double horner_t(const double* c, double x)
+{
+    double s = c[N];
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) s = s * x + c[i];
+    return s;
+}
+
+// solve_bracket with compile-time degree (arrays stay in registers)
+template <int N>
+__device__ __forceinline__ double solve_bracket_t(const double* P, const double* dP, double lo, double hi,
+                                                  bool lo_neg)
+{
+    double xl = lo_neg ? lo : hi;
+    double xh = lo_neg ? hi : lo;
+    double x = 0.5 * (lo + hi);
+    double dxold = fabs(hi - lo);
+    double dx = dxold;
+    double f = horner_t<N>(P, x);
+    double df = horner_t<N - 1>(dP, x);
+    for (int it = 0; it < 300; ++it) {
+        if (f == 0.0) return x;
+        if (f < 0.0) xl = x; else xh = x;
+        const bool bisect = (((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) ||
+                            (fabs(2.0 * f) > fabs(dxold * df));
+        dxold = dx;
+        double xn;
+        if (bisect) {
+            dx = 0.5 * (xh - xl);
+            xn = xl + dx;
+            if (xn == xl || xn == xh) return x;
+        } else {
+            dx = f / df;
+            xn = x - dx;
+            if (xn == x) return x;
+        }
+        x = xn;
+        f = horner_t<N>(P, x);
+        df = horner_t<N - 1>(dP, x);
+    }
+    return x;
+}
+
+
+__device__ __forceinline__ double clamp_b(double v, double B)
+{
+    if (v < -B) v = -B;
+    if (v > B) v = B;
+    return v;
+}
+
+// One interval of one level of real_roots(): P has degree K, dP is its
+// derivative; appends at most one root to cur[0..2].
+template <int K>
+__device__ __forceinline__ void root_interval(const double* P, const double* dP, double lo, double hi, double B,
+                                              bool last, double* cur, int& mcur)
+{
+    lo = clamp_b(lo, B);
+    hi = clamp_b(hi, B);
+    if (!(hi > lo)) return;
+    const double flo = horner_t<K>(P, lo);
+    const double fhi = horner_t<K>(P, hi);
+    bool has = false;
+    double r = 0.0;
+    if (flo == 0.0) {
+        has = true;
+        r = lo;
+    } else if (fhi != 0.0 && ((flo < 0.0) != (fhi < 0.0))) {
+        has = true;
+        r = solve_bracket_t<K>(P, dP, lo, hi, flo < 0.0);
+    } else if (fhi == 0.0 && last) {
+        has = true;
+        r = hi;
+    }
+    if (has) {
+        if (mcur == 0) cur[0] = r;
+        else if (mcur == 1) cur[1] = r;
+        else cur[2] = r;
+        ++mcur;
+    }
+}
+
+// Real roots, ascending, of cin[0..3] (any coefficient may vanish): the
+// sequential statement of real_roots() above, degrees 3, 2 and 1 spelled out.
+__device__ __forceinline__ int real_roots3_thread(const double* cin, double* roots)
+{
+    double cmax = 0.0;
+#pragma unroll
+    for (int i = 0; i <= 3; ++i) cmax = fmax(cmax, fabs(cin[i]));
+    if (!(cmax > 0.0) || !(cmax <= DBL_MAX)) return 0;
+    double c[4];
+#pragma unroll
+    for (int i = 0; i <= 3; ++i) c[i] = cin[i] / cmax;
+    roots[0] = roots[1] = roots[2] = 0.0;
+    if (c[3] != 0.0) {
+        const double D2[3] = {1.0 * c[1], 2.0 * c[2], 3.0 * c[3]};
+        const double D1[2] = {1.0 * D2[1], 2.0 * D2[2]};
+        double B = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) B = fmax(B, fabs(c[i] / c[3]));
+        B = 1.0 + B;
+        if (!(B < 1e25)) B = 1e25;
+        double prev[3] = {-D1[0] / D1[1], 0.0, 0.0};
+        double cur[3] = {0.0, 0.0, 0.0};
+        int mprev = 1, mcur = 0;
+        // level 2: roots of the first derivative
+        root_interval<2>(D2, D1, -B, prev[0], B, false, cur, mcur);
+        root_interval<2>(D2, D1, prev[0], B, B, true, cur, mcur);
+        prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+        mprev = mcur;
+        mcur = 0;
+        // level 3: the polynomial itself, intervals t = 0..mprev
+        root_interval<3>(c, D2, -B, mprev > 0 ? prev[0] : B, B, mprev == 0, cur, mcur);
+        if (mprev >= 1) root_interval<3>(c, D2, prev[0], mprev > 1 ? prev[1] : B, B, mprev == 1, cur, mcur);
+        if (mprev >= 2) root_interval<3>(c, D2, prev[1], B, B, true, cur, mcur);
+        roots[0] = cur[0]; roots[1] = cur[1]; roots[2] = cur[2];
+        return mcur;
+    }
+    if (c[2] != 0.0) {
+        const double D1[2] = {1.0 * c[1], 2.0 * c[2]};
+        double B = 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) B = fmax(B, fabs(c[i] / c[2]));
+        B = 1.0 + B;
+        if (!(B < 1e25)) B = 1e25;
+        const double e = -D1[0] / D1[1];
+        double cur[3] = {0.0, 0.0, 0.0};
+        int mcur = 0;
+        root_interval<2>(c, D1, -B, e, B, false, cur, mcur);
+        root_interval<2>(c, D1, e, B, B, true, cur, mcur);
+        roots[0] = cur[0]; roots[1] = cur[1];
+        return mcur;
+    }
+    if (c[1] != 0.0) {
+        roots[0] = -c[0] / c[1];
+        return 1;
+    }
+    return 0;
+}
+
+#define SFM_SA(i, j) sA[((i) * 9 + (j)) * 64 + lane]
+
+// Seven-point fundamental matrix solver, one thread.  m1/m2: the 7 sampled
+// float32 pixel points.  Up to 3 models into F[3][9]; returns their number.
+__device__ int seven_point_thread(double* sA, int lane, const float* m1, const float* m2, double (*F)[9])
+{
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const double x0 = m1[2 * i], y0 = m1[2 * i + 1], x1 = m2[2 * i], y1 = m2[2 * i + 1];
+        SFM_SA(i, 0) = x1 * x0; SFM_SA(i, 1) = x1 * y0; SFM_SA(i, 2) = x1;
+        SFM_SA(i, 3) = y1 * x0; SFM_SA(i, 4) = y1 * y0; SFM_SA(i, 5) = y1;
+        SFM_SA(i, 6) = x0;      SFM_SA(i, 7) = y0;      SFM_SA(i, 8) = 1.0;
+    }
+    // Gauss-Jordan with complete pivoting (first maximum in row-major scan);
+    // perm holds the column permutation as 4-bit fields
+    unsigned long long perm = 0x876543210ull;
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        int bi = p, bj = p;
+        double best = -1.0;
+#pragma unroll
+        for (int i = p; i < 7; ++i)
+#pragma unroll
+            for (int j = p; j < 9; ++j) {
+                const double v = fabs(SFM_SA(i, j));
+                if (v > best) { best = v; bi = i; bj = j; }
+            }
+        if (!(best > 0.0)) ok = false;
+        // swaps are carried out even when bi == p / bj == p (then they change nothing)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const double a = SFM_SA(p, j), b = SFM_SA(bi, j);
+            SFM_SA(bi, j) = a;
+            SFM_SA(p, j) = b;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const double a = SFM_SA(i, p), b = SFM_SA(i, bj);
+            SFM_SA(i, bj) = a;
+            SFM_SA(i, p) = b;
+        }
+        {
+            const unsigned long long np = (perm >> (4 * p)) & 15ull, nb = (perm >> (4 * bj)) & 15ull;
+            perm &= ~((15ull << (4 * p)) | (15ull << (4 * bj)));
+            perm |= (nb << (4 * p)) | (np << (4 * bj));
+        }
+        const double piv = SFM_SA(p, p);
+        double rowp[9];
+#pragma unroll
+        for (int j = p + 1; j < 9; ++j) {
+            rowp[j] = SFM_SA(p, j) / piv;
+            SFM_SA(p, j) = rowp[j];
+        }
+        SFM_SA(p, p) = 1.0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            if (i == p) continue;
+            const double f = SFM_SA(i, p);
+#pragma unroll
+            for (int j = p + 1; j < 9; ++j) SFM_SA(i, j) = SFM_SA(i, j) - f * rowp[j];
+            SFM_SA(i, p) = 0.0;
+        }
+    }
+    if (!ok) return 0;
+    // basis vectors N0, N1 scattered through the permutation into the (now
+    // unused) first seven columns: N[k][c] at element (k*9 + c) -> slot (t/7, t%7)
+    double nv[2][7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        nv[0][i] = -SFM_SA(i, 7);
+        nv[1][i] = -SFM_SA(i, 8);
+    }
+#define SFM_SN(t) sA[((((t) / 7) * 9) + ((t) % 7)) * 64 + lane]
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int jj = 0; jj < 9; ++jj) {
+            const int col = (int)((perm >> (4 * jj)) & 15ull);
+            const double v = jj < 7 ? nv[k][jj < 7 ? jj : 0] : (jj == 7 + k ? 1.0 : 0.0);
+            const int t = k * 9 + col;
+            sA[(((t / 7) * 9) + (t % 7)) * 64 + lane] = v;
+        }
+    }
+    double f1[9], f2[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        f2[i] = SFM_SN(9 + i);
+        f1[i] = SFM_SN(i) - f2[i];
+    }
+#undef SFM_SN
+    // det(lambda f1 + f2): entries are degree-1 polynomials p[i] = {f2[i], f1[i]}
+    double pp[9][2];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { pp[i][0] = f2[i]; pp[i][1] = f1[i]; }
+    double a[3], b[3], m0[3], mm1[3], mm2[3], t0[4], t1[4], t2[4], c[4];
+    pmul_t<1, 1>(pp[4], pp[8], a); pmul_t<1, 1>(pp[5], pp[7], b);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) m0[i] = a[i] - b[i];
+    pmul_t<1, 1>(pp[3], pp[8], a); pmul_t<1, 1>(pp[5], pp[6], b);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mm1[i] = a[i] - b[i];
+    pmul_t<1, 1>(pp[3], pp[7], a); pmul_t<1, 1>(pp[4], pp[6], b);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mm2[i] = a[i] - b[i];
+    pmul_t<1, 2>(pp[0], m0, t0);
+    pmul_t<1, 2>(pp[1], mm1, t1);
+    pmul_t<1, 2>(pp[2], mm2, t2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = (t0[i] - t1[i]) + t2[i];
+    double roots[3];
+    const int nr = real_roots3_thread(c, roots);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k >= nr) break;
+        double lambda = roots[k], mu = 1.0;
+        const double s = f1[8] * lambda + f2[8];
+        if (fabs(s) > DBL_EPSILON) {
+            mu = 1.0 / s;
+            lambda = lambda * mu;
+            F[k][8] = 1.0;
+        } else {
+            F[k][8] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) F[k][i] = f1[i] * lambda + f2[i] * mu;
+    }
+    return nr;
+}
+#undef SFM_SA
+
 // ---- error functions ---------------------------------------------------------
 
 // Sampson error test: (float)(s^2 / denom) <= tf, with the division skipped
@@ -573,10 +865,9 @@ __device__ __forceinline__ int sampson_inlier(const double* E, double u1, double
 // Symmetric epipolar test: (float)max(d1^2/den1, d2^2/den2) <= tf, evaluated as
 // OpenCV does (reciprocal, then two multiplies) only when the outcome is not
 // already certain from den*t comparisons with 2^-20 relative margins.
-__device__ __forceinline__ int symepi_inlier(const double* F, float fx1, float fy1, float fx2, float fy2,
-                                             float tf, double tlo, double thi)
+__device__ __forceinline__ int symepi_inlier_d(const double* F, double x1, double y1, double x2, double y2,
+                                               float tf, double tlo, double thi)
 {
-    const double x1 = fx1, y1 = fy1, x2 = fx2, y2 = fy2;
     double a = (F[0] * x1 + F[1] * y1) + F[2];
     double b = (F[3] * x1 + F[4] * y1) + F[5];
     double c = (F[6] * x1 + F[7] * y1) + F[8];
@@ -595,6 +886,11 @@ __device__ __forceinline__ int symepi_inlier(const double* F, float fx1, float f
     const double s2 = 1. / den2;
     const double s1 = 1. / den1;
     return (float)fmax(d1 * d1 * s1, d2 * d2 * s2) <= tf ? 1 : 0;
+}
+__device__ __forceinline__ int symepi_inlier(const double* F, float fx1, float fy1, float fx2, float fy2,
+                                             float tf, double tlo, double thi)
+{
+    return symepi_inlier_d(F, (double)fx1, (double)fy1, (double)fx2, (double)fy2, tf, tlo, thi);
 }
 
 // ---- kernels -------------------------------------------------------------------
@@ -616,6 +912,7 @@ __global__ void __launch_bounds__(256) ransac_prep_kernel(const RansacProb* __re
         pb.result[R_VALID] = 0;
         pb.result[R_DIRECT] = 0;
         pb.result[R_N] = n;
+        pb.result[R_NLIST] = 0;
     }
     if (i >= n) return;
     if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
@@ -628,6 +925,11 @@ __global__ void __launch_bounds__(256) ransac_prep_kernel(const RansacProb* __re
         pb.f1[2 * i + 1] = (float)pb.px1[2 * i + 1];
         pb.f2[2 * i] = (float)pb.px2[2 * i];
         pb.f2[2 * i + 1] = (float)pb.px2[2 * i + 1];
+        // the same values widened again: what the error function computes on
+        pb.x1[2 * i] = (double)pb.f1[2 * i];
+        pb.x1[2 * i + 1] = (double)pb.f1[2 * i + 1];
+        pb.x2[2 * i] = (double)pb.f2[2 * i];
+        pb.x2[2 * i + 1] = (double)pb.f2[2 * i + 1];
     }
 }
 
@@ -819,84 +1121,201 @@ __global__ void __launch_bounds__(64) ransac_solve_kernel(const RansacProb* __re
     if (lane == 0) pb.nmodels[hyp] = nm;
 }
 
-// Inlier counts of every candidate model of H consecutive hypotheses over all
-// points: each thread loads a point once and tests it against all their models.
-template <int MODEL, int MAXM, int H>
-__global__ void __launch_bounds__(256)
-ransac_score_kernel(const RansacProb* __restrict__ probs, int hyp0, int n_hyp)
+// Seven-point hypotheses, one thread each (64 per workgroup).
+__global__ void __launch_bounds__(64) ransac_solve7_kernel(const RansacProb* __restrict__ probs, int hyp0, int n_hyp)
 {
-    __shared__ double sM[H * MAXM][9];
-    __shared__ int sNm[H];
-    __shared__ int sCnt[H * MAXM];
+    __shared__ double sA[63 * 64];
     const RansacProb pb = probs[blockIdx.y];
-    const int hypb = hyp0 + blockIdx.x * H;
+    const int lane = threadIdx.x;
+    const int hyp = hyp0 + blockIdx.x * 64 + lane;
+    const bool in_range = hyp < hyp0 + n_hyp;
     const int n = *pb.n_ptr;
-    const int tid = threadIdx.x;
-    if (tid < H) {
-        const int hyp = hypb + tid;
+    bool active = in_range && n >= 7 && hyp < pb.result[R_VALID];
+    int idx[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) idx[k] = 0;
+    if (active) {
+        const int* row = pb.table + (size_t)hyp * 7;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) idx[k] = row[k];
+        if (idx[0] < 0) {  // the row could not be drawn
+            active = false;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) idx[k] = 0;
+        }
+    }
+    // inactive lanes run on seven copies of point 0 (rejected at the first
+    // zero pivot) and drop the result
+    float m1[14], m2[14];
+    if (n > 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const float2 u = ((const float2*)pb.f1)[idx[k]];
+            const float2 v = ((const float2*)pb.f2)[idx[k]];
+            m1[2 * k] = u.x; m1[2 * k + 1] = u.y;
+            m2[2 * k] = v.x; m2[2 * k + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 14; ++k) m1[k] = m2[k] = 0.f;
+    }
+    double F[3][9];
+    const int nm = seven_point_thread(sA, lane, m1, m2, F);
+    if (!in_range) return;
+    if (!active) {
+        pb.nmodels[hyp] = 0;
+        return;
+    }
+    pb.nmodels[hyp] = nm;
+    double* dst = pb.models + (size_t)hyp * 90;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k < nm) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) dst[9 * k + i] = F[k][i];
+        }
+}
+
+// Lists the candidate models of hypotheses [hyp0, hyp0+n_hyp) densely
+// (entry = hyp*10 + q, scan order) and initialises their counts: 0 for an
+// existing model, -1 for none.  One workgroup per problem.
+__global__ void __launch_bounds__(1024) ransac_compact_kernel(const RansacProb* __restrict__ probs, int hyp0,
+                                                              int n_hyp, int maxm)
+{
+    __shared__ int wsum[16];
+    __shared__ int s_running;
+    const RansacProb pb = probs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = *pb.n_ptr;
+    const int valid = pb.result[R_VALID];
+    if (tid == 0) s_running = 0;
+    __syncthreads();
+    for (int h0 = 0; h0 < n_hyp; h0 += 1024) {
+        const int hyp = hyp0 + h0 + tid;
+        const bool in_range = h0 + tid < n_hyp;
         int nm = 0;
-        if (hyp < hyp0 + n_hyp && n >= pb.m && hyp < pb.result[R_VALID]) nm = min(pb.nmodels[hyp], MAXM);
-        sNm[tid] = nm;
+        if (in_range && n >= pb.m && hyp < valid) nm = min(pb.nmodels[hyp], maxm);
+        int incl = nm;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int base = s_running;
+        for (int w = 0; w < wv; ++w) base += wsum[w];
+        const int pos = base + incl - nm;
+        if (in_range) {
+            for (int q = 0; q < MAX_MODELS; ++q) pb.counts[(size_t)hyp * MAX_MODELS + q] = q < nm ? 0 : -1;
+            for (int q = 0; q < nm; ++q) pb.list[pos + q] = hyp * MAX_MODELS + q;
+        }
+        __syncthreads();
+        if (tid == 1023) s_running = base + incl;
+        __syncthreads();
     }
-    if (tid < H * MAXM) sCnt[tid] = 0;
-    __syncthreads();
-    for (int idx = tid; idx < H * MAXM * 9; idx += 256) {
-        const int hh = idx / (MAXM * 9), r = idx - hh * (MAXM * 9);
-        if (r < sNm[hh] * 9) sM[hh * MAXM + r / 9][r % 9] = pb.models[(size_t)(hypb + hh) * 90 + r];
+    if (tid == 0) pb.result[R_NLIST] = s_running;
+}
+
+// den > 0 && den <= DBL_MAX in one instruction: positive normal or denormal
+__device__ __forceinline__ bool pos_finite(double v) { return __builtin_amdgcn_class(v, 0x180); }
+
+// The two tests again for the one-thread-per-model kernel: same arithmetic and
+// same outcome as sampson_inlier / symepi_inlier_d, arranged so that the common
+// case (outcome certain without dividing) has no branch.
+__device__ __forceinline__ int sampson_inlier_u(const double* E, double u1, double v1, double u2, double v2,
+                                                float tf, double tlo, double thi)
+{
+    const double Ex1_0 = (E[0] * u1 + E[1] * v1) + E[2];
+    const double Ex1_1 = (E[3] * u1 + E[4] * v1) + E[5];
+    const double Ex1_2 = (E[6] * u1 + E[7] * v1) + E[8];
+    const double Etx2_0 = (E[0] * u2 + E[3] * v2) + E[6];
+    const double Etx2_1 = (E[1] * u2 + E[4] * v2) + E[7];
+    const double s = (u2 * Ex1_0 + v2 * Ex1_1) + Ex1_2;
+    const double a = Ex1_0 * Ex1_0;
+    const double b = Ex1_1 * Ex1_1;
+    const double c = Etx2_0 * Etx2_0;
+    const double d = Etx2_1 * Etx2_1;
+    const double den = ((a + b) + c) + d;
+    const double s2 = s * s;
+    const bool in = s2 <= den * tlo;
+    const bool out = s2 >= den * thi;
+    int r = (in && !out) ? 1 : 0;
+    if (!(pos_finite(den) && (in || out))) r = (float)(s2 / den) <= tf ? 1 : 0;
+    return r;
+}
+
+__device__ __forceinline__ int symepi_inlier_u(const double* F, double x1, double y1, double x2, double y2,
+                                               float tf, double tlo, double thi)
+{
+    double a = (F[0] * x1 + F[1] * y1) + F[2];
+    double b = (F[3] * x1 + F[4] * y1) + F[5];
+    double c = (F[6] * x1 + F[7] * y1) + F[8];
+    const double den2 = a * a + b * b;
+    const double d2 = (x2 * a + y2 * b) + c;
+    a = (F[0] * x2 + F[3] * y2) + F[6];
+    b = (F[1] * x2 + F[4] * y2) + F[7];
+    c = (F[2] * x2 + F[5] * y2) + F[8];
+    const double den1 = a * a + b * b;
+    const double d1 = (x1 * a + y1 * b) + c;
+    const double n1 = d1 * d1, n2 = d2 * d2;
+    const bool out = (n1 >= den1 * thi) | (n2 >= den2 * thi);
+    const bool in = (n1 <= den1 * tlo) & (n2 <= den2 * tlo);
+    int r = (in && !out) ? 1 : 0;
+    if (!(pos_finite(den1) && pos_finite(den2) && (in || out))) {
+        const double s2 = 1. / den2;
+        const double s1 = 1. / den1;
+        r = (float)fmax(d1 * d1 * s1, d2 * d2 * s2) <= tf ? 1 : 0;
     }
-    int nmv[H];
-    int total = 0;
+    return r;
+}
+
+// Inlier counts: one thread per listed candidate model, which it keeps in
+// registers; the points of the chunk are the same for every lane and are read
+// through scalar loads (nothing writes them while this kernel runs), so a
+// point costs each model nothing but its own arithmetic.
+// grid = (groups of 64 models, point chunks, problems).
+template <int MODEL>
+__global__ void __launch_bounds__(64) ransac_score_kernel(const RansacProb* __restrict__ probs, int chunk_pts)
+{
+    typedef const double __attribute__((address_space(4))) cdouble;
+    const RansacProb pb = probs[blockIdx.z];
+    const int nlist = __builtin_amdgcn_readfirstlane(pb.result[R_NLIST]);
+    const int g0 = blockIdx.x * 64;
+    if (g0 >= nlist) return;
+    const int n = __builtin_amdgcn_readfirstlane(*pb.n_ptr);
+    const int i0 = blockIdx.y * chunk_pts;
+    const int i1 = min(n, i0 + chunk_pts);
+    if (i0 >= i1) return;
+    const int lane = threadIdx.x;
+    const bool active = g0 + lane < nlist;
+    const int e = pb.list[active ? g0 + lane : g0];
+    const double* Mg = pb.models + (size_t)(e / MAX_MODELS) * 90 + (e % MAX_MODELS) * 9;
+    double M[9];
 #pragma unroll
-    for (int hh = 0; hh < H; ++hh) {
-        nmv[hh] = sNm[hh];
-        total += nmv[hh];
-    }
-    __syncthreads();
-    int cnt[H * MAXM];
+    for (int i = 0; i < 9; ++i) M[i] = Mg[i];
+    const float tf = pb.tf;
+    const double tlo = pb.tlo, thi = pb.thi;
+    cdouble* X1 = (cdouble*)(uintptr_t)pb.x1;
+    cdouble* X2 = (cdouble*)(uintptr_t)pb.x2;
+    auto test = [&](double x1, double y1, double x2, double y2) -> int {
+        if (MODEL == SFM_GPU_MODEL_ESSENTIAL) return sampson_inlier_u(M, x1, y1, x2, y2, tf, tlo, thi);
+        return symepi_inlier_u(M, x1, y1, x2, y2, tf, tlo, thi);
+    };
+    int cnt = 0;
+    int i = i0;
+    for (; i + 4 <= i1; i += 4) {
+        double p[8], q[8];
 #pragma unroll
-    for (int c = 0; c < H * MAXM; ++c) cnt[c] = 0;
-    if (total > 0) {
-        if (MODEL == SFM_GPU_MODEL_ESSENTIAL) {
-            const double2* X1 = (const double2*)pb.x1;
-            const double2* X2 = (const double2*)pb.x2;
-            for (int i = tid; i < n; i += 256) {
-                const double2 a = X1[i], b = X2[i];
-#pragma unroll
-                for (int hh = 0; hh < H; ++hh)
-#pragma unroll
-                    for (int q = 0; q < MAXM; ++q)
-                        if (q < nmv[hh])
-                            cnt[hh * MAXM + q] +=
-                                sampson_inlier(sM[hh * MAXM + q], a.x, a.y, b.x, b.y, pb.tf, pb.tlo, pb.thi);
-            }
-        } else {
-            const float2* X1 = (const float2*)pb.f1;
-            const float2* X2 = (const float2*)pb.f2;
-            for (int i = tid; i < n; i += 256) {
-                const float2 a = X1[i], b = X2[i];
-#pragma unroll
-                for (int hh = 0; hh < H; ++hh)
-#pragma unroll
-                    for (int q = 0; q < MAXM; ++q)
-                        if (q < nmv[hh])
-                            cnt[hh * MAXM + q] +=
-                                symepi_inlier(sM[hh * MAXM + q], a.x, a.y, b.x, b.y, pb.tf, pb.tlo, pb.thi);
-            }
+        for (int k = 0; k < 8; ++k) {
+            p[k] = X1[2 * i + k];
+            q[k] = X2[2 * i + k];
         }
 #pragma unroll
-        for (int c = 0; c < H * MAXM; ++c) {
-            int v = cnt[c];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if ((tid & 63) == 0 && v != 0) atomicAdd(&sCnt[c], v);
-        }
+        for (int k = 0; k < 4; ++k) cnt += test(p[2 * k], p[2 * k + 1], q[2 * k], q[2 * k + 1]);
     }
-    __syncthreads();
-    if (tid < H * 10) {
-        const int hh = tid / 10, q = tid - hh * 10;
-        const int hyp = hypb + hh;
-        if (hyp < hyp0 + n_hyp) pb.counts[(size_t)hyp * 10 + q] = q < sNm[hh] ? sCnt[hh * MAXM + q] : -1;
-    }
+    for (; i < i1; ++i) cnt += test(X1[2 * i], X1[2 * i + 1], X2[2 * i], X2[2 * i + 1]);
+    if (active && cnt != 0) atomicAdd(&pb.counts[e], cnt);
 }
 
 // Fixed-count winner: the first (hypothesis, model) in scan order whose count is
@@ -990,22 +1409,26 @@ hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int
     hipLaunchKernelGGL(ransac_table_fixed_kernel, dim3((nrows + 255) / 256, n_prob), dim3(256), 0, s, probs, nrows);
     return hipGetLastError();
 }
-hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int hyp0, int n_hyp)
+hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp)
 {
-    hipLaunchKernelGGL(ransac_solve_kernel, dim3(n_hyp, n_prob), dim3(64), 0, s, probs, hyp0);
+    if (model == SFM_GPU_MODEL_FUNDAMENTAL)
+        hipLaunchKernelGGL(ransac_solve7_kernel, dim3((n_hyp + 63) / 64, n_prob), dim3(64), 0, s, probs, hyp0, n_hyp);
+    else
+        hipLaunchKernelGGL(ransac_solve_kernel, dim3(n_hyp, n_prob), dim3(64), 0, s, probs, hyp0);
     return hipGetLastError();
 }
-hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp)
+hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
+                               int n_hyp)
 {
-    if (model == SFM_GPU_MODEL_ESSENTIAL) {
-        constexpr int H = 1;
-        hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL, 10, H>), dim3((n_hyp + H - 1) / H, n_prob),
-                           dim3(256), 0, s, probs, hyp0, n_hyp);
-    } else {
-        constexpr int H = 1;
-        hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL, 3, H>), dim3((n_hyp + H - 1) / H, n_prob),
-                           dim3(256), 0, s, probs, hyp0, n_hyp);
-    }
+    const int maxm = model == SFM_GPU_MODEL_ESSENTIAL ? 10 : 3;
+    hipLaunchKernelGGL(ransac_compact_kernel, dim3(n_prob), dim3(1024), 0, s, probs, hyp0, n_hyp, maxm);
+    const int chunk = 512;
+    const dim3 grid(((size_t)n_hyp * maxm + 63) / 64, (cap + chunk - 1) / chunk > 0 ? (cap + chunk - 1) / chunk : 1,
+                    n_prob);
+    if (model == SFM_GPU_MODEL_ESSENTIAL)
+        hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL>, grid, dim3(64), 0, s, probs, chunk);
+    else
+        hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL>, grid, dim3(64), 0, s, probs, chunk);
     return hipGetLastError();
 }
 hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp)
