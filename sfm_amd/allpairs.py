@@ -1,0 +1,185 @@
+"""Exhaustive (or ring) pair matching over several GPUs, one process per GPU.
+
+The reference matches image i against image i+1 in a sequential loop
+(/root/reference/main.cpp:167-173).  Pairs are independent, so the loop is
+sharded: images are block-owned by rank, prepared once where they live, their
+prepared blocks are exchanged with ONE all-gather (RCCL over xGMI on GPUs), the
+pair list is dealt over the ranks, and the V x V result matrices are summed
+with one all-reduce.  Nothing else crosses ranks.
+
+The arithmetic is behind a small backend interface so that the exchange and
+the dealing can be exercised on CPU with the gloo backend:
+
+    backend.prepare(local_images) -> (blobs [n_local, blob_bytes] uint8 tensor,
+                                      rows  [n_local] int32 tensor)
+    backend.blob_bytes(max_rows)  -> int
+    backend.match(blobs [V, blob_bytes], rows [V], pairs [P, 2])
+                                  -> (n_good [P], n_inliers [P]) int arrays
+
+`GpuBackend` is the product path (libsfm_gpu.so); there is no CPU backend in
+this package.
+"""
+import numpy as np
+
+
+def pair_list(n_images, mode="all"):
+    """Pairs (i, j) to match.  "ring": i -> (i+1) mod V, the reference's loop
+    (main.cpp:167-173); "all": every i < j."""
+    V = int(n_images)
+    if mode == "ring":
+        if V < 2:
+            return np.zeros((0, 2), np.int32)
+        return np.array([[i, (i + 1) % V] for i in range(V)], np.int32)
+    if mode == "all":
+        return np.array([[i, j] for i in range(V) for j in range(i + 1, V)], np.int32).reshape(-1, 2)
+    raise ValueError("unknown pair mode %r" % (mode,))
+
+
+def owned_range(n_images, world, rank):
+    """Contiguous block of images a rank owns (sizes differ by at most one)."""
+    base, extra = divmod(int(n_images), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def deal_pairs(pairs, rows, world):
+    """Assigns every pair to a rank: pairs sorted by descending cost
+    (rows_i * rows_j, ties by pair index) are dealt to the currently least
+    loaded rank.  Deterministic, identical on every rank.  Returns a list of
+    index arrays, one per rank, each ascending."""
+    pairs = np.asarray(pairs).reshape(-1, 2)
+    rows = np.asarray(rows, dtype=np.int64)
+    cost = rows[pairs[:, 0]] * rows[pairs[:, 1]] if len(pairs) else np.zeros(0, np.int64)
+    order = np.lexsort((np.arange(len(pairs)), -cost))
+    load = np.zeros(world, np.int64)
+    out = [[] for _ in range(world)]
+    for p in order:
+        r = int(np.argmin(load))  # first minimum: deterministic
+        out[r].append(int(p))
+        load[r] += int(cost[p]) + 1
+    return [np.array(sorted(o), np.int64) for o in out]
+
+
+def match_all_pairs(local_images, n_images, backend, mode="all", group=None, device=None):
+    """Matches all pairs of `n_images` images spread over the ranks of `group`.
+
+    local_images: this rank's images, in global order (owned_range()).
+    Returns (pairs [P,2], n_good [V,V], n_inliers [V,V]) on every rank; the
+    matrices hold pair (i, j) at [i, j] and zeros elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    V = int(n_images)
+    lo, hi = owned_range(V, world, rank)
+    if len(local_images) != hi - lo:
+        raise ValueError("rank %d owns images [%d, %d) but was given %d" % (rank, lo, hi, len(local_images)))
+
+    # 1. agree on the block size (largest image anywhere)
+    local_max = max([backend.rows_of(im) for im in local_images] + [0])
+    t = torch.tensor([local_max], dtype=torch.int64, device=device)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    max_rows = int(t.item())
+    blob_bytes = backend.blob_bytes(max_rows)
+
+    # 2. prepare where the images live
+    blobs, rows = backend.prepare(local_images, max_rows)
+    per_rank = (V + world - 1) // world  # owned_range gives at most this many
+    if distributed and world > 1:
+        # 3. one all-gather of equally sized slabs (short ranks pad with zeros)
+        slab = torch.zeros((per_rank, blob_bytes), dtype=torch.uint8, device=blobs.device)
+        slab_rows = torch.zeros(per_rank, dtype=torch.int32, device=blobs.device)
+        slab[: hi - lo] = blobs
+        slab_rows[: hi - lo] = rows
+        all_slabs = torch.empty((world * per_rank, blob_bytes), dtype=torch.uint8, device=blobs.device)
+        all_rows = torch.empty(world * per_rank, dtype=torch.int32, device=blobs.device)
+        dist.all_gather_into_tensor(all_slabs, slab, group=group)
+        dist.all_gather_into_tensor(all_rows, slab_rows, group=group)
+        index = []
+        for r in range(world):
+            rlo, rhi = owned_range(V, world, r)
+            index += [r * per_rank + k for k in range(rhi - rlo)]
+        index = torch.tensor(index, dtype=torch.int64, device=blobs.device)
+        all_blobs = all_slabs.index_select(0, index) if len(index) != world * per_rank else all_slabs
+        all_rows = all_rows.index_select(0, index)
+    else:
+        all_blobs, all_rows = blobs, rows
+
+    # 4. deal the pairs, run this rank's share
+    pairs = pair_list(V, mode)
+    rows_host = all_rows.cpu().numpy()
+    mine = deal_pairs(pairs, rows_host, world)[rank]
+    good = torch.zeros((V, V), dtype=torch.int64, device=device)
+    inl = torch.zeros((V, V), dtype=torch.int64, device=device)
+    if len(mine):
+        ng, ni = backend.match(all_blobs, rows_host, pairs[mine])
+        pi = torch.as_tensor(pairs[mine, 0].astype(np.int64), device=device)
+        pj = torch.as_tensor(pairs[mine, 1].astype(np.int64), device=device)
+        good[pi, pj] = torch.as_tensor(np.asarray(ng, dtype=np.int64), device=device)
+        inl[pi, pj] = torch.as_tensor(np.asarray(ni, dtype=np.int64), device=device)
+
+    # 5. one all-reduce of the result matrices
+    if distributed and world > 1:
+        both = torch.stack([good, inl])
+        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+        good, inl = both[0], both[1]
+    return pairs, good.cpu().numpy(), inl.cpu().numpy()
+
+
+class GpuBackend:
+    """libsfm_gpu.so on the current GPU.  An image is (descriptors [n,128]
+    float32/uint8 numpy array or CUDA tensor, keypoints [n,2] float32)."""
+
+    def __init__(self, ctx, **match_kwargs):
+        self.ctx = ctx
+        self.match_kwargs = match_kwargs
+
+    @staticmethod
+    def rows_of(image):
+        return int(image[0].shape[0])
+
+    @staticmethod
+    def blob_bytes(max_rows):
+        from . import matcher
+        return matcher.image_packed_bytes(max_rows)
+
+    def prepare(self, images, max_rows):
+        import torch
+        from . import matcher
+        blk = matcher.image_packed_bytes(max_rows)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        blobs = torch.zeros((len(images), blk), dtype=torch.uint8, device=dev)
+        rows = torch.tensor([self.rows_of(im) for im in images], dtype=torch.int32, device=dev)
+        keep = []
+        for k, (desc, kp) in enumerate(images):
+            d = torch.as_tensor(np.ascontiguousarray(desc) if isinstance(desc, np.ndarray) else desc).to(dev)
+            p = torch.as_tensor(np.ascontiguousarray(kp, dtype=np.float32) if isinstance(kp, np.ndarray)
+                                else kp).to(dev).contiguous()
+            d = d.contiguous()
+            dtype = matcher.DESC_U8 if d.dtype == torch.uint8 else matcher.DESC_F32
+            if dtype == matcher.DESC_F32 and d.dtype != torch.float32:
+                raise TypeError("descriptors must be float32 or uint8")
+            keep.append((d, p))
+            if d.shape[0] > 0:
+                matcher.prepare_many(self.ctx, [d.data_ptr()], [d.shape[0]], d.stride(0) * d.element_size(),
+                                     dtype, [p.data_ptr()], [blobs[k].data_ptr()])
+        matcher.check_inputs(self.ctx)  # also waits, so `keep` may go
+        return blobs, rows
+
+    def match(self, blobs, rows, pairs):
+        from . import matcher
+        used = sorted(set(int(v) for v in np.asarray(pairs).reshape(-1)))
+        remap = {g: k for k, g in enumerate(used)}
+        imgs = [matcher.WrappedImage(self.ctx, blobs[g].data_ptr(), int(rows[g])) for g in used]
+        local_pairs = np.array([[remap[int(a)], remap[int(b)]] for a, b in pairs], np.int32)
+        try:
+            ng, ni = matcher.match_pairs(self.ctx, imgs, local_pairs, self.match_kwargs.get("K"),
+                                         **{k: v for k, v in self.match_kwargs.items() if k != "K"})
+        finally:
+            for im in imgs:
+                im.close()
+        return ng, ni

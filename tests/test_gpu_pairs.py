@@ -115,3 +115,31 @@ def test_match_pairs_fundamental_and_ragged_sizes(gpu_ctx, oracle):
         assert (sel[p]["trainIdx"] == osel["trainIdx"]).all()
     for im in imgs:
         im.close()
+
+
+def test_allpairs_driver_single_process_equals_match_pairs(gpu_ctx):
+    """sfm_amd.allpairs with the GPU backend (world size 1: same code path as a
+    rank of a multi-GPU job minus the two collectives) against direct
+    match_pairs calls on owned images."""
+    from sfm_amd import allpairs
+    sizes = [1500, 2048, 1100, 1900]
+    rng = np.random.default_rng(9)
+    pool = synth.sift_like(2048, 41)
+    images = []
+    for n in sizes:
+        d = pool[rng.permutation(2048)[:n]].copy()
+        d = np.clip(d + rng.integers(-4, 5, d.shape), 0, 255).astype(np.float32)
+        kp = np.stack([rng.uniform(0, synth.IMG_W, n), rng.uniform(0, synth.IMG_H, n)], 1).astype(np.float32)
+        images.append((d, kp))
+    kw = dict(K=None, ratio=0.7, model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED, prob=0.99,
+              threshold=3.0, n_hyp=64)
+    pairs, good, inl = allpairs.match_all_pairs(images, len(images), allpairs.GpuBackend(gpu_ctx, **kw),
+                                                mode="all")
+    assert pairs.tolist() == allpairs.pair_list(4, "all").tolist()
+    owned = [matcher.Image(gpu_ctx, d, k) for d, k in images]
+    ng, ni = matcher.match_pairs(gpu_ctx, owned, pairs, None, **{k: v for k, v in kw.items() if k != "K"})
+    for (i, j), g, n in zip(pairs, ng, ni):
+        assert good[i, j] == g and inl[i, j] == n
+    assert good.sum() == ng.sum() and inl.sum() == ni.sum() and ng.sum() > 0
+    for im in owned:
+        im.close()
