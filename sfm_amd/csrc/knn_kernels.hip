@@ -35,51 +35,96 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t p)
 }
 
 // ------------------------------------------------------------ prep_rows ----
-// One wave per row: converts 128 values to int8 (v - 128), validates them and
-// writes the per-row constants.  Rows n..rows_alloc-1 are written as padding.
+// 8 lanes per row, 32 rows per workgroup: converts 128 values to int8
+// (v - 128), validates them and writes the per-row constants.  Rows
+// n..rows_alloc-1 are written as padding.  Every load instruction reads whole
+// 128-B pieces of 8 rows and every store writes whole 128-B rows.
+__device__ __forceinline__ uint32_t pack4_checked(float a, float b, float c, float d, bool& bad)
+{
+    const int ia = (int)a, ib = (int)b, ic = (int)c, id = (int)d;
+    bad |= !(a >= 0.f && a <= 255.f && b >= 0.f && b <= 255.f && c >= 0.f && c <= 255.f && d >= 0.f &&
+             d <= 255.f) ||
+           (float)ia != a || (float)ib != b || (float)ic != c || (float)id != d;
+    return ((uint32_t)(ia & 255) | ((uint32_t)(ib & 255) << 8) | ((uint32_t)(ic & 255) << 16) |
+            ((uint32_t)(id & 255) << 24)) ^ 0x80808080u;
+}
+
 template <int DTYPE>
 __global__ void __launch_bounds__(256) prep_rows_kernel(const PrepJob* __restrict__ jobs, int32_t* err_flag)
 {
+    constexpr int TS = 36;  // dwords per transposition row (16-B aligned, spreads banks)
+    __shared__ __attribute__((aligned(16))) uint32_t tr[32 * TS];
     const PrepJob job = jobs[blockIdx.y];
     const ImageDev img = job.img;
+    if ((int)blockIdx.x * 32 >= img.rows_alloc) return;
     const unsigned char* src = job.src;
     const size_t step = job.step;
     const int n = img.n;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= img.rows_alloc) return;
-    int v0 = 128, v1 = 128;
+    const int rl = threadIdx.x >> 3;  // row within the workgroup
+    const int seg = threadIdx.x & 7;
+    const int row = blockIdx.x * 32 + rl;
+    const bool wide = (((uintptr_t)src | step) & 15) == 0;  // 16-B loads allowed
+    uint32_t P[4] = {0u, 0u, 0u, 0u};  // value 128 -> byte 0
     bool bad = false;
     if (row < n) {
+        const unsigned char* rp = src + (size_t)row * step;
         if (DTYPE == SFM_GPU_DESC_F32) {
-            const float2 f = *(const float2*)(src + (size_t)row * step + lane * 8);
-            v0 = (int)f.x;
-            v1 = (int)f.y;
-            bad = !(f.x >= 0.f && f.x <= 255.f && f.y >= 0.f && f.y <= 255.f) ||
-                  (float)v0 != f.x || (float)v1 != f.y;
+            // piece j of the lane: values 32j + 4seg .. +3
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* fp = (const float*)rp + j * 32 + seg * 4;
+                float4 f;
+                if (wide) f = *(const float4*)fp;
+                else f = make_float4(fp[0], fp[1], fp[2], fp[3]);
+                P[j] = pack4_checked(f.x, f.y, f.z, f.w, bad);
+            }
         } else {
-            const unsigned short u = *(const unsigned short*)(src + (size_t)row * step + lane * 2);
-            v0 = u & 255;
-            v1 = u >> 8;
+            // the lane's 16 consecutive bytes
+            const unsigned char* bp = rp + seg * 16;
+            if (wide) {
+                const uint4 u = *(const uint4*)bp;
+                P[0] = u.x; P[1] = u.y; P[2] = u.z; P[3] = u.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    P[j] = (uint32_t)bp[4 * j] | ((uint32_t)bp[4 * j + 1] << 8) | ((uint32_t)bp[4 * j + 2] << 16) |
+                           ((uint32_t)bp[4 * j + 3] << 24);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) P[j] ^= 0x80808080u;
         }
     }
     if (bad) {
-        v0 = v1 = 128;
+        P[0] = P[1] = P[2] = P[3] = 0u;
         atomicOr(err_flag, 1);
     }
-    const int b0 = v0 - 128, b1 = v1 - 128;
-    const unsigned short packed = (unsigned short)((b0 & 255) | ((b1 & 255) << 8));
-    *(unsigned short*)(img.desc + (size_t)row * DIM + lane * 2) = packed;
-    int n2 = b0 * b0 + b1 * b1;
-    int s = b0 + b1;
+    int n2 = 0, sm = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        n2 += __shfl_xor(n2, off);
-        s += __shfl_xor(s, off);
+    for (int j = 0; j < 4; ++j) {
+        n2 = __builtin_amdgcn_sdot4((int)P[j], (int)P[j], n2, false);
+        sm = __builtin_amdgcn_sdot4((int)P[j], 0x01010101, sm, false);
     }
-    if (lane == 0) {
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) {
+        n2 += __shfl_xor(n2, off);
+        sm += __shfl_xor(sm, off);
+    }
+    if (row >= img.rows_alloc) return;
+    uint4 o;
+    if (DTYPE == SFM_GPU_DESC_F32) {
+        // the 8 lanes of a row belong to one wave: exchange through LDS needs
+        // no workgroup barrier
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tr[rl * TS + j * 8 + seg] = P[j];
+        __builtin_amdgcn_wave_barrier();
+        o = *(const uint4*)&tr[rl * TS + seg * 4];
+    } else {
+        o = make_uint4(P[0], P[1], P[2], P[3]);
+    }
+    *(uint4*)(img.desc + (size_t)row * DIM + seg * 16) = o;
+    if (seg == 0) {
         if (row < n) {
-            const int tn = n2 + 2 * s;  // = sum (v-127)^2 - 128, in [-128, 2097024]
+            const int tn = n2 + 2 * sm;  // = sum (v-127)^2 - 128, in [-128, 2097024]
             img.qn[row] = n2;
             img.cin[row] = (tn >> 1) + KEY_OFFSET;  // arithmetic shift = floor
             if (job.kp_src && img.kp) img.kp[row] = job.kp_src[row];
@@ -441,10 +486,13 @@ __device__ __forceinline__ void insert3(u64& a1, u64& a2, u64& a3, u64 v)
 //     minima), or if d2 >= 2^22 where different d2 share one float sqrt, the
 //     query is queued for the exhaustive float-ranked pass instead.
 __global__ void __launch_bounds__(256)
-knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k)
+knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblocks, int map_mode)
 {
-    const KnnJob job = jobs[blockIdx.y];
-    const int q = blockIdx.x * 8 + (threadIdx.x >> 5);
+    // same workgroup -> XCD affinity as the sweep: the gathers of one job's
+    // train rows then hit a single L2
+    const WgCoord wg = decode_wg(blockIdx.x, (uint32_t)qblocks, 1u, map_mode);
+    const KnnJob job = jobs[wg.job];
+    const int q = wg.qblock * 8 + (threadIdx.x >> 5);
     const int l = threadIdx.x & 31;
     if (q >= job.n_query) return;  // whole 32-lane group leaves together
     const u64 NONE = ~0ull;
@@ -722,7 +770,7 @@ __global__ void __launch_bounds__(64) mfma_layout_probe_kernel(const int8_t* A, 
 hipError_t launch_prep_rows(hipStream_t s, const PrepJob* jobs_dev, int n_jobs, int rows_alloc_max,
                             int dtype, int32_t* err_flag)
 {
-    const dim3 grid((rows_alloc_max + 3) / 4, n_jobs);
+    const dim3 grid((rows_alloc_max + 31) / 32, n_jobs);
     if (dtype == SFM_GPU_DESC_F32)
         hipLaunchKernelGGL(prep_rows_kernel<SFM_GPU_DESC_F32>, grid, dim3(256), 0, s, jobs_dev, err_flag);
     else
@@ -789,8 +837,12 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
 hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_query_max,
                                int n_splits, int k)
 {
-    const dim3 grid((n_query_max + 7) / 8, n_jobs);
-    hipLaunchKernelGGL(knn_rescan_kernel, grid, dim3(256), 0, s, jobs_dev, n_splits, k);
+    const int qblocks = (n_query_max + 7) / 8;
+    if (qblocks <= 0 || n_jobs <= 0) return hipSuccess;
+    const long long total = (long long)qblocks * n_jobs;
+    if (total > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(knn_rescan_kernel, dim3((unsigned)total), dim3(256), 0, s, jobs_dev, n_splits, k, qblocks,
+                       n_jobs % 8 == 0 ? 1 : 0);
     return hipGetLastError();
 }
 

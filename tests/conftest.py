@@ -21,6 +21,11 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def gpu_ctx():
+    # PyTorch brings its own copy of the HIP runtime: when both live in one
+    # process torch has to initialise first (bench.py does the same).
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    torch.cuda.init()
     from sfm_amd import matcher
     ctx = matcher.Context(0)
     yield ctx

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Writes the fixtures in this directory.
+
+The reference repository holds no test vectors for the matching path and its
+arithmetic lives in OpenCV, which is not installed here, so these fixtures are
+NOT outputs of the reference: they are outputs of the CPU oracle (oracle/) on
+seeded synthetic inputs, frozen so that (a) a change in the oracle shows up as
+a diff against history and (b) the GPU path is checked against bytes that do
+not depend on the oracle being rebuilt.  Inputs are stored too, so the files
+are self-contained.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import pyoracle as po
+from sfm_amd import synth
+
+
+def knn_case():
+    Q, T, planted = synth.planted_pair(300, 421, 11, 12, 13)
+    # a few exact duplicates (distance ties -> ascending train index) and a far row
+    T[7] = T[3]
+    T[400] = T[3]
+    Q[5] = T[3]
+    Q[6] = 0
+    T[9] = 255
+    m, c = po.knn_match(Q, T, 2)
+    keep = po.ratio_test(m, c, 0.7)
+    np.savez_compressed(os.path.join(HERE, "knn_small.npz"), query=Q.astype(np.uint8), train=T.astype(np.uint8),
+                        trainIdx=m["trainIdx"], distance=m["distance"], counts=c, keep=keep)
+
+
+def ransac_case(name, model, n, seed, hyps):
+    p1, p2, K, inl = synth.two_view(n, seed, 0.6, 0.4)
+    Kuse = K if model == po.MODEL_ESSENTIAL else None
+    thr = 1.0 if model == po.MODEL_ESSENTIAL else 3.0
+    fixed = po.ransac(p1, p2, Kuse, model=model, prob=0.99, threshold=thr, fixed_count=hyps, want_counts=True)
+    adaptive = po.ransac(p1, p2, Kuse, model=model, prob=0.99, threshold=thr, max_iters=300)
+    np.savez_compressed(
+        os.path.join(HERE, name), pts1=p1, pts2=p2, K=K, threshold=thr, hyps=hyps,
+        fixed_ok=fixed["ok"], fixed_mask=fixed["mask"], fixed_model=fixed["model"],
+        fixed_n_inliers=fixed["n_inliers"], fixed_counts=fixed["counts"],
+        adaptive_ok=adaptive["ok"], adaptive_mask=adaptive["mask"], adaptive_model=adaptive["model"],
+        adaptive_n_inliers=adaptive["n_inliers"], adaptive_iters=adaptive["iters"])
+
+
+def main():
+    knn_case()
+    ransac_case("ransac_essential.npz", po.MODEL_ESSENTIAL, 400, 21, 96)
+    ransac_case("ransac_fundamental.npz", po.MODEL_FUNDAMENTAL, 500, 22, 128)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

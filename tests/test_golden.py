@@ -1,0 +1,83 @@
+"""Frozen fixtures (tests/golden/, written by tests/golden/make_golden.py).
+
+They are outputs of the CPU oracle on seeded inputs, not of the reference
+(which holds no vectors for this path and whose arithmetic is OpenCV's): they
+pin the oracle against drift and give the GPU path a target that does not
+depend on the oracle library being present or rebuilt."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))  # allow_pickle stays False
+
+
+# ---- CPU: the oracle still reproduces its frozen outputs -----------------
+
+def test_oracle_reproduces_knn_golden(oracle):
+    g = load("knn_small.npz")
+    m, c = oracle.knn_match(g["query"].astype(np.float32), g["train"].astype(np.float32), 2)
+    assert (m["trainIdx"] == g["trainIdx"]).all()
+    assert (m["distance"].view(np.uint32) == g["distance"].view(np.uint32)).all()
+    assert (c == g["counts"]).all()
+    assert (oracle.ratio_test(m, c, 0.7) == g["keep"]).all()
+    # the duplicates planted in the fixture: ties resolve to ascending train index
+    assert g["trainIdx"][5].tolist() == [3, 7] and g["distance"][5].tolist() == [0.0, 0.0]
+
+
+@pytest.mark.parametrize("name,model", [("ransac_essential.npz", 0), ("ransac_fundamental.npz", 1)])
+def test_oracle_reproduces_ransac_golden(oracle, name, model):
+    g = load(name)
+    K = g["K"] if model == 0 else None
+    thr = float(g["threshold"])
+    f = oracle.ransac(g["pts1"], g["pts2"], K, model=model, prob=0.99, threshold=thr,
+                      fixed_count=int(g["hyps"]), want_counts=True)
+    assert f["ok"] == int(g["fixed_ok"]) and f["n_inliers"] == int(g["fixed_n_inliers"])
+    assert (f["mask"] == g["fixed_mask"]).all() and (f["counts"] == g["fixed_counts"]).all()
+    assert (f["model"].view(np.uint64) == g["fixed_model"].view(np.uint64)).all()
+    a = oracle.ransac(g["pts1"], g["pts2"], K, model=model, prob=0.99, threshold=thr, max_iters=300)
+    assert a["iters"] == int(g["adaptive_iters"]) and (a["mask"] == g["adaptive_mask"]).all()
+    assert (a["model"].view(np.uint64) == g["adaptive_model"].view(np.uint64)).all()
+
+
+# ---- GPU: the HIP path against the same bytes -----------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_gpu_knn_equals_golden(gpu_ctx, dtype):
+    from sfm_amd import matcher
+    g = load("knn_small.npz")
+    m, c = matcher.BFMatcher(gpu_ctx).knnMatch(g["query"].astype(dtype), g["train"].astype(dtype), k=2)
+    assert (m["trainIdx"] == g["trainIdx"]).all()
+    assert (m["distance"].view(np.uint32) == g["distance"].view(np.uint32)).all()
+    assert (c == g["counts"]).all()
+    assert (matcher.ratio_test(m, c, 0.7) == g["keep"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,model", [("ransac_essential.npz", 0), ("ransac_fundamental.npz", 1)])
+def test_gpu_ransac_equals_golden(gpu_ctx, name, model):
+    from sfm_amd import matcher
+    g = load(name)
+    thr = float(g["threshold"])
+    hyps = int(g["hyps"])
+    if model == 0:
+        _, mask, r = matcher.findEssentialMat(gpu_ctx, g["pts1"], g["pts2"], g["K"], prob=0.99, threshold=thr,
+                                              mode=matcher.RANSAC_FIXED, n_hyp=hyps)
+        _, amask, ar = matcher.findEssentialMat(gpu_ctx, g["pts1"], g["pts2"], g["K"], prob=0.99,
+                                                threshold=thr, maxIters=300)
+    else:
+        _, mask, r = matcher.findFundamentalMat(gpu_ctx, g["pts1"], g["pts2"], ransacReprojThreshold=thr,
+                                                confidence=0.99, mode=matcher.RANSAC_FIXED, n_hyp=hyps)
+        _, amask, ar = matcher.findFundamentalMat(gpu_ctx, g["pts1"], g["pts2"], ransacReprojThreshold=thr,
+                                                  confidence=0.99, maxIters=300)
+    assert r["ok"] == int(g["fixed_ok"]) and r["n_inliers"] == int(g["fixed_n_inliers"])
+    assert (mask == g["fixed_mask"]).all()
+    np.testing.assert_allclose(r["model"], g["fixed_model"], rtol=1e-6, atol=0)  # stated tolerance
+    assert (np.asarray(r["model"]).view(np.uint64) == g["fixed_model"].view(np.uint64)).all()  # and in fact equal
+    assert ar["iters"] == int(g["adaptive_iters"]) and (amask == g["adaptive_mask"]).all()
+    assert (np.asarray(ar["model"]).view(np.uint64) == g["adaptive_model"].view(np.uint64)).all()
