@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--n-desc", type=int, default=8192)
     ap.add_argument("--hyps", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--score-filter", type=int, default=1, help="debug: 0 = double precision only")
     args = ap.parse_args()
 
     import torch
@@ -95,6 +96,8 @@ def main():
         d_packed = torch.empty((2 * B, blk), dtype=torch.uint8, device="cuda")
     stream.synchronize()
     ctx = matcher.Context(local_rank, stream=stream.cuda_stream)
+    if args.score_filter != 1:
+        ctx._L.sfm_gpu_debug_set_score_filter(args.score_filter)
     desc_ptrs = [d_desc[i].data_ptr() for i in range(2 * B)]
     kp_ptrs = [d_kp[i].data_ptr() for i in range(2 * B)]
     packed_ptrs = [d_packed[i].data_ptr() for i in range(2 * B)]

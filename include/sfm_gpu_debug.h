@@ -31,6 +31,12 @@ int sfm_gpu_debug_mfma_probe(sfm_gpu_ctx* ctx, const int8_t* a, const int8_t* b,
 int sfm_gpu_debug_ransac_dump(sfm_gpu_ctx* ctx, int n_hyp, int32_t* table, int32_t* nmodels,
                               int32_t* counts, double* models);
 
+/* 0: the RANSAC scoring kernel evaluates every (model, point) pair in double
+ * precision only; 1 (default): a float32 filter with a rigorous error bound
+ * settles the clear cases first.  Both give identical counts; the switch lets
+ * tests prove it.  Process-wide. */
+int sfm_gpu_debug_set_score_filter(int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "ransac_dev.h"
+#include "sfm_gpu_debug.h"
 #include "sfm_ctx.h"
 
 using namespace sfm;
@@ -50,6 +51,7 @@ size_t ransac_ws_bytes(int cap, int hyp_cap, int m)
     size_t b = 0;
     b += align_up((size_t)cap * 16, 256) * 2;            // x1, x2
     b += align_up((size_t)cap * 8, 256) * 2;             // f1, f2
+    b += align_up((size_t)(cap + 2) * 16, 256);          // soa
     b += align_up((size_t)hyp_cap * m * 4, 256);         // table
     b += align_up((size_t)hyp_cap * 90 * 8, 256);        // models
     b += align_up((size_t)hyp_cap * 4, 256);             // nmodels
@@ -68,6 +70,8 @@ void carve_ransac(RansacProb& pb, char* base, int cap, int hyp_cap, int m)
     pb.x2 = (double*)take((size_t)cap * 16);
     pb.f1 = (float*)take((size_t)cap * 8);
     pb.f2 = (float*)take((size_t)cap * 8);
+    pb.cap_pad = (cap + 2) & ~1;
+    pb.soa = (float*)take((size_t)(cap + 2) * 16);
     pb.table = (int32_t*)take((size_t)hyp_cap * m * 4);
     pb.models = (double*)take((size_t)hyp_cap * 90 * 8);
     pb.nmodels = (int32_t*)take((size_t)hyp_cap * 4);
@@ -270,6 +274,12 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
 }  // namespace
 
 extern "C" {
+
+int sfm_gpu_debug_set_score_filter(int on)
+{
+    sfm::set_ransac_score_filter(on);
+    return SFM_GPU_OK;
+}
 
 int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int n, const double* K,
                    int model, double prob, double threshold_px, int max_iters, int mode,

@@ -19,6 +19,7 @@ enum {
     R_RNG_LO = 8,
     R_N = 9,       // copy of the point count
     R_NLIST = 10,  // candidate models listed for the batch being scored
+    R_MAXABS = 11, // largest |coordinate| of the problem's points, float32 bits
     R_COUNT = 16
 };
 
@@ -32,6 +33,7 @@ struct RansacProb {
     double* x2;
     float* f1;             // [cap][2] float32 pixels (fundamental model)
     float* f2;
+    float* soa;            // [4][cap_pad] float32 planes X1, Y1, X2, Y2 of x1/x2
     int32_t* table;        // [hyp_cap][m]
     double* models;        // [hyp_cap][MAX_MODELS][9]
     int32_t* nmodels;      // [hyp_cap]
@@ -45,6 +47,7 @@ struct RansacProb {
     float tf;              // (float)(threshold^2), threshold already scaled
     int32_t model;         // SFM_GPU_MODEL_*
     int32_t m;             // minimal sample size: 5 or 7
+    int32_t cap_pad;       // plane stride of soa (even, >= cap)
 };
 
 hipError_t launch_ransac_prep(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
@@ -53,6 +56,7 @@ hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int
 hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp);
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
                                int n_hyp);
+void set_ransac_score_filter(int on);
 hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp);
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
 

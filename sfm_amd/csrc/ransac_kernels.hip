@@ -913,6 +913,7 @@ __global__ void __launch_bounds__(256) ransac_prep_kernel(const RansacProb* __re
         pb.result[R_DIRECT] = 0;
         pb.result[R_N] = n;
         pb.result[R_NLIST] = 0;
+        pb.result[R_MAXABS] = 0;
     }
     if (i >= n) return;
     if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
@@ -931,6 +932,13 @@ __global__ void __launch_bounds__(256) ransac_prep_kernel(const RansacProb* __re
         pb.x2[2 * i] = (double)pb.f2[2 * i];
         pb.x2[2 * i + 1] = (double)pb.f2[2 * i + 1];
     }
+    // float32 planes X1, Y1, X2, Y2 of the coordinates the error function works
+    // on (exact for the fundamental model, rounded for the essential one): the
+    // scoring kernel's single-precision filter reads pairs of points from them
+    pb.soa[0 * (size_t)pb.cap_pad + i] = (float)pb.x1[2 * i];
+    pb.soa[1 * (size_t)pb.cap_pad + i] = (float)pb.x1[2 * i + 1];
+    pb.soa[2 * (size_t)pb.cap_pad + i] = (float)pb.x2[2 * i];
+    pb.soa[3 * (size_t)pb.cap_pad + i] = (float)pb.x2[2 * i + 1];
 }
 
 struct CvRng {
@@ -1189,6 +1197,23 @@ __global__ void __launch_bounds__(1024) ransac_compact_kernel(const RansacProb* 
     const int n = *pb.n_ptr;
     const int valid = pb.result[R_VALID];
     if (tid == 0) s_running = 0;
+    // largest |coordinate| over the problem's points, as float bits (non-negative
+    // floats order like their bit patterns); the filter's error bounds use it
+    {
+        int mx = 0;
+        for (int i = tid; i < n; i += 1024)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                mx = max(mx, __float_as_int(fabsf(pb.soa[(size_t)c * pb.cap_pad + i])));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+        if (lane == 0) wsum[wv] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 16; ++w) mx = max(mx, wsum[w]);
+            pb.result[R_MAXABS] = mx;
+        }
+    }
     __syncthreads();
     for (int h0 = 0; h0 < n_hyp; h0 += 1024) {
         const int hyp = hyp0 + h0 + tid;
@@ -1270,21 +1295,145 @@ __device__ __forceinline__ int symepi_inlier_u(const double* F, double x1, doubl
     return r;
 }
 
+// ---- single-precision filter ---------------------------------------------------
+// Most (model, point) tests are nowhere near the threshold, and for those a
+// float32 evaluation with a rigorous error bound gives the same answer as the
+// double-precision procedure at a fraction of the cost (packed f32 FMAs, two
+// points per instruction).  Only the evaluations the bound cannot settle are
+// redone exactly.
+//
+// Bound.  u = 2^-24.  Every coordinate has |x| <= R.  For a row (p,q,r) of the
+// model, a = p*x + q*y + r evaluated as fma(p,x,fma(q,y,r)) on float-rounded
+// inputs differs from the double-precision value by at most
+// da = 8u*((|p|+|q|)R + |r|) =: 8u*A, and the residual d = x'*a + y'*b + c by at
+// most dd = 16u*(R(A+B)+C).  With 2|v|e <= eps*v^2 + e^2/eps,
+//     d*^2   in  d^2 (1 -+ eps) -+ Kn,   Kn = dd^2 (1 + 1/eps)
+//     den*   in  den (1 -+ eps) -+ Kd,   Kd = (da^2 + db^2 [+ ...]) (1 + 1/eps)
+// (starred = double-precision values), so
+//     d^2 (1+eps) + Kn <= (den (1-eps) - Kd) T-   proves  d*^2/den* <= T-
+//     d^2 (1-eps) - Kn >= (den (1+eps) + Kd) T+   proves  d*^2/den* >= T+
+// with T-+ = tf (1 -+ 2^-16), inside which the double-precision procedure
+// (2^-20 margins, then a float-rounded quotient) cannot decide otherwise.  The
+// constants carry 2^-18 of extra slack for the roundings of the test itself.
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+struct FilterConst {
+    float c1, c2, c3, c4;  // multipliers of d^2 and den in the two tests
+    float kin[2], kout[2]; // additive terms per side (side 1 only for Sampson)
+};
+
+__device__ __forceinline__ float f_up(double v) { return (float)(v * (1.0 + 1.0 / 1048576.0)); }
+__device__ __forceinline__ float f_down(double v) { return (float)(v * (1.0 - 1.0 / 1048576.0)); }
+
+template <int MODEL>
+__device__ __forceinline__ FilterConst make_filter(const double* M, double R, float tf)
+{
+    const double u = 1.0 / 16777216.0, eps = 1.0 / 512.0, g = 1.0 + 1.0 / 262144.0;
+    const double Rr = R * (1.0 + 1.0 / 1048576.0);
+    double m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = fabs(M[i]);
+    const double Tin = (double)tf * (1.0 - 1.0 / 65536.0), Tout = (double)tf * (1.0 + 1.0 / 65536.0);
+    const double ke = (1.0 + 1.0 / eps) * (1.0 + 1.0 / 1024.0);
+    double kn[2], kd[2], smax;
+    // rows of the model against (x1,y1,1): A_i = (|m[3i]|+|m[3i+1]|) R + |m[3i+2]|
+    const double r0 = (m[0] + m[1]) * Rr + m[2], r1 = (m[3] + m[4]) * Rr + m[5], r2 = (m[6] + m[7]) * Rr + m[8];
+    // columns against (x2,y2,1)
+    const double q0 = (m[0] + m[3]) * Rr + m[6], q1 = (m[1] + m[4]) * Rr + m[7], q2 = (m[2] + m[5]) * Rr + m[8];
+    if (MODEL == SFM_GPU_MODEL_FUNDAMENTAL) {
+        const double s2 = Rr * (r0 + r1) + r2;  // residual of side 2 (rows, then x2)
+        const double s1 = Rr * (q0 + q1) + q2;  // residual of side 1 (columns, then x1)
+        kn[0] = (16 * u * s1) * (16 * u * s1) * ke;
+        kd[0] = ((8 * u * q0) * (8 * u * q0) + (8 * u * q1) * (8 * u * q1)) * ke;
+        kn[1] = (16 * u * s2) * (16 * u * s2) * ke;
+        kd[1] = ((8 * u * r0) * (8 * u * r0) + (8 * u * r1) * (8 * u * r1)) * ke;
+        smax = fmax(fmax(s1, s2), fmax(fmax(r0, r1), fmax(q0, q1)));
+    } else {
+        const double ss = Rr * (r0 + r1) + r2;
+        kn[0] = (16 * u * ss) * (16 * u * ss) * ke;
+        kd[0] = ((8 * u * r0) * (8 * u * r0) + (8 * u * r1) * (8 * u * r1) + (8 * u * q0) * (8 * u * q0) +
+                 (8 * u * q1) * (8 * u * q1)) * ke;
+        kn[1] = kn[0];
+        kd[1] = kd[0];
+        smax = fmax(fmax(ss, fmax(q0, q1)), fmax(r0, r1));
+    }
+    FilterConst f;
+    f.c1 = f_up((1.0 + eps) * g);
+    f.c2 = f_down((1.0 - eps) * Tin / g);
+    f.c3 = f_down((1.0 - eps) / g);
+    f.c4 = f_up((1.0 + eps) * Tout * g);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        f.kin[k] = f_up(fmax((kn[k] + kd[k] * Tin) * g, 1e-30));
+        f.kout[k] = f_up(fmax((kn[k] + kd[k] * Tout) * g, 1e-30));
+    }
+    // anything that could overflow or is not a number: no test can pass
+    const bool ok = (smax * smax * fmax(1.0, (double)f.c4) * 8.0 < 1e37) && (R < 1e18) && (tf > 1e-12f) &&
+                    (tf < 1e12f);
+    if (!ok) {
+        f.kin[0] = f.kin[1] = f.kout[0] = f.kout[1] = __builtin_inff();
+    }
+    return f;
+}
+
+__device__ __forceinline__ f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2v splat(float v) { return (f2v)(v); }
+__device__ __forceinline__ f2v max2(f2v a, f2v b)
+{
+    f2v r;
+    r.x = fmaxf(a.x, b.x);
+    r.y = fmaxf(a.y, b.y);
+    return r;
+}
+
+// Two points against one model: h_in <= 0 proves an inlier, h_out >= 0 an outlier.
+template <int MODEL>
+__device__ __forceinline__ void filter_pair(const float* Mf, const FilterConst& fc, f2v x1, f2v y1, f2v x2, f2v y2,
+                                            f2v& h_in, f2v& h_out)
+{
+    const f2v a = fma2(splat(Mf[0]), x1, fma2(splat(Mf[1]), y1, splat(Mf[2])));
+    const f2v b = fma2(splat(Mf[3]), x1, fma2(splat(Mf[4]), y1, splat(Mf[5])));
+    const f2v c = fma2(splat(Mf[6]), x1, fma2(splat(Mf[7]), y1, splat(Mf[8])));
+    const f2v d2 = fma2(x2, a, fma2(y2, b, c));
+    const f2v at = fma2(splat(Mf[0]), x2, fma2(splat(Mf[3]), y2, splat(Mf[6])));
+    const f2v bt = fma2(splat(Mf[1]), x2, fma2(splat(Mf[4]), y2, splat(Mf[7])));
+    const f2v n2 = d2 * d2;
+    if (MODEL == SFM_GPU_MODEL_FUNDAMENTAL) {
+        const f2v ct = fma2(splat(Mf[2]), x2, fma2(splat(Mf[5]), y2, splat(Mf[8])));
+        const f2v d1 = fma2(x1, at, fma2(y1, bt, ct));
+        const f2v n1 = d1 * d1;
+        const f2v den2 = fma2(a, a, b * b);
+        const f2v den1 = fma2(at, at, bt * bt);
+        const f2v hi1 = fma2(n1, splat(fc.c1), fma2(den1, splat(-fc.c2), splat(fc.kin[0])));
+        const f2v hi2 = fma2(n2, splat(fc.c1), fma2(den2, splat(-fc.c2), splat(fc.kin[1])));
+        const f2v ho1 = fma2(n1, splat(fc.c3), fma2(den1, splat(-fc.c4), splat(-fc.kout[0])));
+        const f2v ho2 = fma2(n2, splat(fc.c3), fma2(den2, splat(-fc.c4), splat(-fc.kout[1])));
+        h_in = max2(hi1, hi2);    // both sides must prove "in"
+        h_out = max2(ho1, ho2);   // either side may prove "out"
+    } else {
+        const f2v den = fma2(a, a, fma2(b, b, fma2(at, at, bt * bt)));
+        h_in = fma2(n2, splat(fc.c1), fma2(den, splat(-fc.c2), splat(fc.kin[0])));
+        h_out = fma2(n2, splat(fc.c3), fma2(den, splat(-fc.c4), splat(-fc.kout[0])));
+    }
+}
+
 // Inlier counts: one thread per listed candidate model, which it keeps in
 // registers; the points of the chunk are the same for every lane and are read
 // through scalar loads (nothing writes them while this kernel runs), so a
 // point costs each model nothing but its own arithmetic.
 // grid = (groups of 64 models, point chunks, problems).
 template <int MODEL>
-__global__ void __launch_bounds__(64) ransac_score_kernel(const RansacProb* __restrict__ probs, int chunk_pts)
+__global__ void __launch_bounds__(64) ransac_score_kernel(const RansacProb* __restrict__ probs, int chunk_pts,
+                                                          int use_filter)
 {
     typedef const double __attribute__((address_space(4))) cdouble;
+    typedef const f2v __attribute__((address_space(4))) cf2v;
     const RansacProb pb = probs[blockIdx.z];
     const int nlist = __builtin_amdgcn_readfirstlane(pb.result[R_NLIST]);
     const int g0 = blockIdx.x * 64;
     if (g0 >= nlist) return;
     const int n = __builtin_amdgcn_readfirstlane(*pb.n_ptr);
-    const int i0 = blockIdx.y * chunk_pts;
+    const int i0 = blockIdx.y * chunk_pts;  // chunk_pts is even
     const int i1 = min(n, i0 + chunk_pts);
     if (i0 >= i1) return;
     const int lane = threadIdx.x;
@@ -1298,23 +1447,70 @@ __global__ void __launch_bounds__(64) ransac_score_kernel(const RansacProb* __re
     const double tlo = pb.tlo, thi = pb.thi;
     cdouble* X1 = (cdouble*)(uintptr_t)pb.x1;
     cdouble* X2 = (cdouble*)(uintptr_t)pb.x2;
-    auto test = [&](double x1, double y1, double x2, double y2) -> int {
-        if (MODEL == SFM_GPU_MODEL_ESSENTIAL) return sampson_inlier_u(M, x1, y1, x2, y2, tf, tlo, thi);
-        return symepi_inlier_u(M, x1, y1, x2, y2, tf, tlo, thi);
+    auto exact = [&](int i) -> int {
+        if (MODEL == SFM_GPU_MODEL_ESSENTIAL)
+            return sampson_inlier_u(M, X1[2 * i], X1[2 * i + 1], X2[2 * i], X2[2 * i + 1], tf, tlo, thi);
+        return symepi_inlier_u(M, X1[2 * i], X1[2 * i + 1], X2[2 * i], X2[2 * i + 1], tf, tlo, thi);
     };
     int cnt = 0;
     int i = i0;
-    for (; i + 4 <= i1; i += 4) {
-        double p[8], q[8];
+    // Tests the filter cannot settle are parked per lane (offset within the
+    // chunk) and redone in double precision after the sweep, so that one
+    // lane's doubt does not make the other 63 wait at every such point.
+    constexpr int QCAP = 40;
+    __shared__ unsigned short parked[QCAP * 64];
+    int n_parked = 0;
+    if (use_filter) {
+        const float R = __int_as_float(__builtin_amdgcn_readfirstlane(pb.result[R_MAXABS]));
+        const FilterConst fc = make_filter<MODEL>(M, (double)R, tf);
+        float Mf[9];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            p[k] = X1[2 * i + k];
-            q[k] = X2[2 * i + k];
+        for (int k = 0; k < 9; ++k) Mf[k] = (float)M[k];
+        const size_t cp = (size_t)pb.cap_pad;
+        typedef const float __attribute__((address_space(4))) cfloat;
+        cfloat* S = (cfloat*)(uintptr_t)pb.soa;
+        auto park = [&](int idx) {
+            if (use_filter == 2) return;  // timing experiment: unsettled tests are dropped (wrong counts)
+            if (n_parked < QCAP) {
+                parked[n_parked * 64 + lane] = (unsigned short)(idx - i0);
+                ++n_parked;
+            } else {
+                cnt += exact(idx);
+            }
+        };
+        // four points per step, the next four already on their way
+        const int i4 = i0 + ((i1 - i0) & ~3);
+        f2v nx[8];
+        auto fetch = [&](int at) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                nx[2 * c] = *(cf2v*)(S + c * cp + at);
+                nx[2 * c + 1] = *(cf2v*)(S + c * cp + at + 2);
+            }
+        };
+        if (i < i4) fetch(i);
+        for (; i < i4; i += 4) {
+            f2v cur[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cur[k] = nx[k];
+            fetch(i + 4 < i4 ? i + 4 : i);  // the last step re-reads its own points
+            f2v hinA, houtA, hinB, houtB;
+            filter_pair<MODEL>(Mf, fc, cur[0], cur[2], cur[4], cur[6], hinA, houtA);
+            filter_pair<MODEL>(Mf, fc, cur[1], cur[3], cur[5], cur[7], hinB, houtB);
+            const bool in0 = hinA.x <= 0.f, in1 = hinA.y <= 0.f, in2 = hinB.x <= 0.f, in3 = hinB.y <= 0.f;
+            cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0) + (in2 ? 1 : 0) + (in3 ? 1 : 0);
+            const bool u0 = !(in0 || houtA.x >= 0.f), u1 = !(in1 || houtA.y >= 0.f);
+            const bool u2 = !(in2 || houtB.x >= 0.f), u3 = !(in3 || houtB.y >= 0.f);
+            if (u0 || u1 || u2 || u3) {
+                if (u0) park(i);
+                if (u1) park(i + 1);
+                if (u2) park(i + 2);
+                if (u3) park(i + 3);
+            }
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cnt += test(p[2 * k], p[2 * k + 1], q[2 * k], q[2 * k + 1]);
     }
-    for (; i < i1; ++i) cnt += test(X1[2 * i], X1[2 * i + 1], X2[2 * i], X2[2 * i + 1]);
+    for (; i < i1; ++i) cnt += exact(i);
+    for (int k = 0; k < n_parked; ++k) cnt += exact(i0 + (int)parked[k * 64 + lane]);
     if (active && cnt != 0) atomicAdd(&pb.counts[e], cnt);
 }
 
@@ -1393,6 +1589,10 @@ __global__ void __launch_bounds__(256) ransac_mask_kernel(const RansacProb* __re
 
 }  // namespace
 
+// test hook: 0 scores every point in double precision only
+int g_score_filter = 1;
+void set_ransac_score_filter(int on) { g_score_filter = on; }
+
 hipError_t launch_ransac_prep(hipStream_t s, const RansacProb* probs, int n_prob, int cap)
 {
     hipLaunchKernelGGL(ransac_prep_kernel, dim3((cap + 255) / 256 > 0 ? (cap + 255) / 256 : 1, n_prob),
@@ -1426,9 +1626,11 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     const dim3 grid(((size_t)n_hyp * maxm + 63) / 64, (cap + chunk - 1) / chunk > 0 ? (cap + chunk - 1) / chunk : 1,
                     n_prob);
     if (model == SFM_GPU_MODEL_ESSENTIAL)
-        hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL>, grid, dim3(64), 0, s, probs, chunk);
+        hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL>, grid, dim3(64), 0, s, probs, chunk,
+                           g_score_filter);
     else
-        hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL>, grid, dim3(64), 0, s, probs, chunk);
+        hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL>, grid, dim3(64), 0, s, probs, chunk,
+                           g_score_filter);
     return hipGetLastError();
 }
 hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp)
