@@ -38,7 +38,8 @@ def knn_case():
 
 
 def ransac_case(name, model, n, seed, hyps):
-    p1, p2, K, inl = synth.two_view(n, seed, 0.6, 0.4)
+    p1, p2, _, _ = synth.two_view(n, seed, 0.6, 0.4)
+    K = synth.REF_K
     Kuse = K if model == po.MODEL_ESSENTIAL else None
     thr = 1.0 if model == po.MODEL_ESSENTIAL else 3.0
     fixed = po.ransac(p1, p2, Kuse, model=model, prob=0.99, threshold=thr, fixed_count=hyps, want_counts=True)

@@ -140,3 +140,59 @@ def test_full_size_4096_hyps_properties(gpu_ctx):
     assert (mask.astype(bool) & ~is_in).sum() < 30
     assert abs(np.linalg.det(E)) < 1e-10
     assert min(np.abs(E - E_true).max(), np.abs(E + E_true).max()) < 0.02
+
+
+def _near_threshold_problem(model, seed, n_clean, n_edge, thr_px):
+    """Correspondences of one true geometry: `n_clean` exact ones and `n_edge`
+    whose second point is pushed off its epipolar line by thr*(1 +- 2 %), so
+    that for hypotheses drawn from the clean ones a large share of the tests
+    lands inside the band the float32 filter cannot settle."""
+    rng = np.random.default_rng(seed)
+    p1, p2, _, E = synth.two_view(n_clean + n_edge, seed, inlier_frac=1.0, noise_px=0.0)
+    K = synth.REF_K
+    Kinv = np.linalg.inv(K)
+    F = Kinv.T @ E @ Kinv
+    h1 = np.concatenate([p1, np.ones((len(p1), 1))], 1)
+    l2 = h1 @ F.T                                   # epipolar lines in image 2
+    nrm = l2[:, :2] / np.linalg.norm(l2[:, :2], axis=1, keepdims=True)
+    # the Sampson error of a one-sided displacement d is about d^2 / 2
+    scale = np.sqrt(2.0) if model == 0 else 1.0
+    delta = scale * thr_px * (1.0 + rng.uniform(-0.02, 0.02, len(p1))) * rng.choice([-1.0, 1.0], len(p1))
+    delta[:n_clean] = 0.0
+    p2 = p2 + nrm * delta[:, None]
+    p1 = p1.astype(np.float32).astype(np.float64)
+    p2 = p2.astype(np.float32).astype(np.float64)
+    m = 5 if model == 0 else 7
+    table = np.stack([rng.permutation(n_clean)[:m] for _ in range(192)]).astype(np.int32)
+    return p1, p2, table
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_scoring_filter_is_exact_on_near_threshold_points(gpu_ctx, oracle, model):
+    thr = 1.0 if model == 0 else 3.0
+    p1, p2, table = _near_threshold_problem(model, 77 + model, 1500, 4500, thr)
+    K = synth.REF_K if model == 0 else None
+    o = oracle.ransac(p1, p2, K, model=model, prob=0.99, threshold=thr, fixed_count=len(table),
+                      sample_table=table, want_counts=True)
+    res = {}
+    for filt in (1, 0):
+        gpu_ctx._L.sfm_gpu_debug_set_score_filter(filt)
+        try:
+            if model == 0:
+                _, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, K, prob=0.99, threshold=thr,
+                                                      mode=matcher.RANSAC_FIXED, sample_table=table)
+            else:
+                _, mask, r = matcher.findFundamentalMat(gpu_ctx, p1, p2, ransacReprojThreshold=thr,
+                                                        confidence=0.99, mode=matcher.RANSAC_FIXED,
+                                                        sample_table=table)
+        finally:
+            gpu_ctx._L.sfm_gpu_debug_set_score_filter(1)
+        _, _, counts, _ = _dump(gpu_ctx, len(table), 5 if model == 0 else 7)
+        res[filt] = (counts.copy(), mask.copy(), r["n_inliers"])
+        assert (counts == o["counts"]).all()
+        assert (mask == o["mask"]).all() and r["n_inliers"] == o["n_inliers"]
+    assert (res[0][0] == res[1][0]).all()
+    # the construction did its job: the best model splits the edge points, neither
+    # all in nor all out, so many tests sat near the threshold
+    best = o["counts"].max()
+    assert 1500 + 200 < best < 6000 - 200
