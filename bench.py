@@ -104,14 +104,15 @@ def main():
     images = [matcher.WrappedImage(ctx, packed_ptrs[i], n) for i in range(2 * B)]
     pairs = np.array([[2 * p, 2 * p + 1] for p in range(B)], np.int32)
 
+    row_bytes = 128 * 4  # float32 descriptors, densely packed
+
     def step():
-        matcher.prepare_many(ctx, desc_ptrs, [n] * (2 * B), n_desc_step, matcher.DESC_F32, kp_ptrs,
+        matcher.prepare_many(ctx, desc_ptrs, [n] * (2 * B), row_bytes, matcher.DESC_F32, kp_ptrs,
                              packed_ptrs)
         return matcher.match_pairs(ctx, images, pairs, None, ratio=0.7,
                                    model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED,
                                    prob=0.99, threshold=3.0, n_hyp=nh)
 
-    n_desc_step = 128 * 4
     for _ in range(args.warmup):
         n_good, n_inl = step()
     matcher.check_inputs(ctx)
@@ -121,6 +122,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # timed region: HIP events only around the dominant kernel (roofline figure)
+    ctx.profile_select("knn2_mfma")
     ctx.profile_enable(True)
     ctx.profile_reset()
     fence()
@@ -129,6 +132,13 @@ def main():
         n_good, n_inl = step()
     fence()
     elapsed = time.perf_counter() - t0
+    knn_ms, knn_cnt = ctx.profile_query("knn2_mfma")
+    # per-kernel breakdown from two more steps outside the timed region
+    ctx.profile_select(None)
+    ctx.profile_reset()
+    for _ in range(2):
+        step()
+    ctx.synchronize()
     kern = {}
     for name in ("prep_rows", "knn2_mfma", "knn_finalize", "knn_redo", "ratio_compact", "ransac_prep",
                  "ransac_table", "ransac_solve", "ransac_score", "ransac_select", "ransac_mask",
@@ -146,7 +156,7 @@ def main():
     if rank == 0:
         total_pairs = B * args.steps * world
         value = total_pairs / elapsed
-        knn = kern.get("knn2_mfma", {"avg_us": float("nan"), "launches": 0})
+        knn = {"avg_us": round(knn_ms / max(knn_cnt, 1) * 1e3, 2), "launches": knn_cnt}
         ops_per_launch = 2.0 * n * n * 128 * B
         achieved = ops_per_launch / (knn["avg_us"] * 1e-6) / 1e12
         traffic = None
@@ -191,7 +201,7 @@ def main():
                 "ops_per_launch": ops_per_launch,
                 "avg_launch_us": knn["avg_us"],
             },
-            "kernels": kern,
+            "kernels_outside_timed_region": kern,
         }
         if not args.no_cpu_baseline:
             threads = int(os.environ.get("OMP_NUM_THREADS", "8"))

@@ -233,6 +233,10 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
  * "ransac_select".  Has no counterpart in the reference.
  */
 int sfm_gpu_profile_enable(sfm_gpu_ctx* ctx, int on);
+/* Restricts the timing to one named kernel (NULL: all of them), so that a
+ * throughput measurement can carry the timer of its dominant kernel without
+ * paying for events around every launch. */
+int sfm_gpu_profile_select(sfm_gpu_ctx* ctx, const char* kernel);
 int sfm_gpu_profile_reset(sfm_gpu_ctx* ctx);
 int sfm_gpu_profile_query(sfm_gpu_ctx* ctx, const char* kernel, double* total_ms, int64_t* launches);
 

@@ -85,6 +85,7 @@ def lib():
                                       c.c_int]
     L.sfm_gpu_profile_enable.argtypes = [vp, c.c_int]
     L.sfm_gpu_profile_reset.argtypes = [vp]
+    L.sfm_gpu_profile_select.argtypes = [vp, c.c_char_p]
     L.sfm_gpu_profile_query.argtypes = [vp, c.c_char_p, c.POINTER(c.c_double),
                                         c.POINTER(c.c_int64)]
     L.sfm_gpu_debug_set_knn_variant.argtypes = [vp, c.c_int]

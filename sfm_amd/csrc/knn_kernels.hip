@@ -257,15 +257,28 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
     // wave-instruction moves 8 rows.
     const int dma_r = lane >> 3;
     const int dma_cs = lane & 7;
-    auto issue_stage = [&](int bufi, int row0) {
+    constexpr int PIECES = ST / 8 / WAVES;  // 1-KiB pieces of a stage moved by each wave
+    static_assert(WAVES % 2 == 0, "the swizzle term of a lane must not depend on the piece");
+    // piece k = wave + j*WAVES covers rows 8k..8k+7; for r = 8k + dma_r the term
+    // (r >> 1) & 7 is 4*(k & 1) | (dma_r >> 1), the same for every j: one lane
+    // offset serves all pieces, the rest of the address is uniform
+    const uint32_t dma_off =
+        (uint32_t)((8 * wave + dma_r) * DIM + ((dma_cs ^ (4 * (wave & 1) | (dma_r >> 1))) << 4));
+    const uint32_t cin_off = (uint32_t)(lane & (ST / 4 - 1)) * 16u;
+    auto issue_piece = [&](int bufi, int row0, int j) {
         unsigned char* dst = lds + bufi * LDS_STAGE;
+        const int8_t* base = job.t_desc + (size_t)row0 * DIM + (size_t)j * (WAVES * 1024);
+        glds16(base + dma_off, dst + (wave + j * WAVES) * 1024);
+    };
+    auto issue_cin = [&](int bufi, int row0) {
+        unsigned char* dst = lds + bufi * LDS_STAGE;
+        const unsigned char* base = (const unsigned char*)(job.t_cin + row0);
+        if (wave == WAVES - 1 && lane < ST / 4) glds16(base + cin_off, dst + LDS_DESC);
+    };
+    auto issue_stage = [&](int bufi, int row0) {
 #pragma unroll
-        for (int k = wave; k < ST / 8; k += WAVES) {
-            const int r = 8 * k + dma_r;
-            const int cc = dma_cs ^ ((r >> 1) & 7);
-            glds16(job.t_desc + (size_t)(row0 + r) * DIM + cc * 16, dst + k * 1024);
-        }
-        if (wave == WAVES - 1 && lane < ST / 4) glds16(job.t_cin + row0 + lane * 4, dst + LDS_DESC);
+        for (int j = 0; j < PIECES; ++j) issue_piece(bufi, row0, j);
+        issue_cin(bufi, row0);
     };
 
     // Fragment addresses inside a stage buffer.  The swizzle term of row
@@ -282,6 +295,8 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
     v16i acc[2];   // accumulators of the current / previous unit
     constexpr int U = (ST / 32) * QB;  // units per stage
     constexpr int PARTS = 8 / QB;      // LDS reads issued per unit
+    constexpr int DMA_STEP = (U - 2) / (ST / 8 / WAVES + 1) > 0 ? (U - 2) / (ST / 8 / WAVES + 1) : 1;
+    static_assert(2 + (ST / 8 / WAVES) * DMA_STEP < U, "not enough units to spread the DMA over");
 
     const int n_stage = (c1 - c0) * (CHUNK / ST);
     const int row_base = c0 * CHUNK;
@@ -355,22 +370,26 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
                         fc[nset][4 * (part - 4) + 3] = c[3];
                     }
                 }
-                if (u == 1) {
+                if (u == 1 && ABLATE < 4) {
                     // stage s+1 has landed (this wave's share, then everyone's), and
                     // every wave is past its last read of stage s-1
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     SFM_SB();
-                    if (s + 2 < n_stage) issue_stage(nx2, row_base + (s + 2) * ST);
                 }
+                // the DMA of stage s+2 is spread over the units after the barrier, one
+                // piece at a time, instead of stalling this wave's MFMA stream in a burst
+                // (past the end the last stage is fetched again into the free buffer
+                // rather than branching around the issue)
+                if (u == 1 && ABLATE < 3) issue_stage(nx2, row_base + min(s + 2, n_stage - 1) * ST);
                 SFM_SB();
                 acc[u & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][1], bq[qb][1], acc[u & 1], 0, 0, 0);
                 SFM_SB();
-                if (ABLATE != 2) tmin = minima_lo(pa);
+                if (ABLATE < 2) tmin = minima_lo(pa);
                 SFM_SB();
                 acc[u & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][2], bq[qb][2], acc[u & 1], 0, 0, 0);
                 SFM_SB();
-                if (ABLATE != 2) {
+                if (ABLATE < 2) {
                     tmin = minima_hi(tmin, pa);
                     p = (tmin << TILE_BITS) | ptile;
                     if (u == 0) p |= first;
@@ -378,7 +397,7 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
                 SFM_SB();
                 acc[u & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][3], bq[qb][3], acc[u & 1], 0, 0, 0);
                 SFM_SB();
-                if (ABLATE != 2) {
+                if (ABLATE < 2) {
                     const uint32_t n3 = umin32(m3[pqb], umax32(m2[pqb], p));
                     const uint32_t n2 = umed3(m1[pqb], m2[pqb], p);
                     m1[pqb] = umin32(m1[pqb], p);
@@ -392,8 +411,10 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
             first = 0;
             cur = nxt;
         }
+        // nothing of this workgroup may still be in flight towards LDS when it ends
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // digest of the very last unit
-        if (ABLATE != 2) {
+        if (ABLATE < 2) {
             const v16i& pa = acc[(U - 1) & 1];
             const uint32_t tmin = minima_hi(minima_lo(pa), pa);
             const uint32_t p = (tmin << TILE_BITS) | (uint32_t)(n_stage * (ST / 32) - 1);
@@ -827,6 +848,8 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
         case 3: SFM_KNN2(4, 8, 0); break;
         default:
             if (plan.ablate == 2) SFM_KNN2(4, 4, 2);
+            else if (plan.ablate == 3) SFM_KNN2(4, 4, 3);
+            else if (plan.ablate == 4) SFM_KNN2(4, 4, 4);
             else SFM_KNN2(4, 4, 0);
             break;
     }

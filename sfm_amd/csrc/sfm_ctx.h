@@ -113,7 +113,18 @@ struct sfm_gpu_ctx {
     int dbg_hyp_cap = 0, dbg_m = 0;
 
     bool profiling = false;
+    std::string profile_only;  // empty: every named kernel is timed
     std::map<std::string, sfm::KernelTimer> timers;
+    std::vector<hipEvent_t> event_pool;  // events are reused, not created per launch
+    bool take_event(hipEvent_t* e)
+    {
+        if (!event_pool.empty()) {
+            *e = event_pool.back();
+            event_pool.pop_back();
+            return true;
+        }
+        return hipEventCreate(e) == hipSuccess;
+    }
 
     int fail(int code, const char* fmt, ...)
     {
@@ -137,9 +148,10 @@ struct ProfScope {
     ProfScope(sfm_gpu_ctx* ctx, const char* name) : c(ctx)
     {
         if (!c->profiling) return;
+        if (!c->profile_only.empty() && c->profile_only != name) return;
         t = &c->timers[name];
         t->name = name;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { t = nullptr; return; }
+        if (!c->take_event(&a) || !c->take_event(&b)) { t = nullptr; return; }
         (void)hipEventRecord(a, c->stream);
     }
     ~ProfScope()

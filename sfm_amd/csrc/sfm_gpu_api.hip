@@ -165,9 +165,10 @@ void sfm_gpu_destroy(sfm_gpu_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->timers)
         for (auto& pr : kv.second.pending) {
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
+            c->event_pool.push_back(pr.first);
+            c->event_pool.push_back(pr.second);
         }
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->raw_q, &c->raw_t, &c->partial, &c->out, &c->counts, &c->redo, &c->jobs,
                       &c->flags, &c->prepjobs, &c->rs_pts, &c->rs_table, &c->rs_models, &c->rs_counts, &c->rs_mask,
                       &c->rs_misc, &c->mp_good, &c->mp_pts, &c->mp_ngood};
@@ -387,6 +388,13 @@ int sfm_gpu_profile_enable(sfm_gpu_ctx* c, int on)
     return SFM_GPU_OK;
 }
 
+int sfm_gpu_profile_select(sfm_gpu_ctx* c, const char* kernel)
+{
+    if (!c) return SFM_GPU_ERR_ARG;
+    c->profile_only = kernel ? kernel : "";
+    return SFM_GPU_OK;
+}
+
 static int drain_timers(sfm_gpu_ctx* c)
 {
     SFM_HIP(c, hipStreamSynchronize(c->stream));
@@ -397,8 +405,8 @@ static int drain_timers(sfm_gpu_ctx* c)
                 kv.second.total_ms += ms;
                 kv.second.launches++;
             }
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
+            c->event_pool.push_back(pr.first);
+            c->event_pool.push_back(pr.second);
         }
         kv.second.pending.clear();
     }

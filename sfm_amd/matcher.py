@@ -56,6 +56,9 @@ class Context:
     def profile_enable(self, on=True):
         self.check(self._L.sfm_gpu_profile_enable(self.handle, 1 if on else 0))
 
+    def profile_select(self, kernel=None):
+        self.check(self._L.sfm_gpu_profile_select(self.handle, kernel.encode() if kernel else None))
+
     def profile_reset(self):
         self.check(self._L.sfm_gpu_profile_reset(self.handle))
 
