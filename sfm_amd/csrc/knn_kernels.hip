@@ -18,6 +18,7 @@
 // (float distance, ascending train index) order whenever d2 < 2^22.  The rare
 // queries where that shortcut is not provably exact go through an exhaustive
 // float-ranked pass.
+#include <algorithm>
 #include <type_traits>
 
 #include "sfm_internal.h"
@@ -528,7 +529,12 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
         if (r.z != 0xFFFFFFFFu) insert3(c1, c2, c3, ((u64)(r.z >> TILE_BITS) << 32) | 0xFFFFFFFFu);
     };
     if (n_splits == 1) {
-        take(job.partial[q]);
+        // a single record is already in ascending (x, tile, half) order
+        const uint4 r = job.partial[q];
+        const uint32_t t0 = r.w & 0x3FFFFFFFu;
+        if (r.x != 0xFFFFFFFFu) c1 = ((u64)(r.x >> TILE_BITS) << 32) | (((t0 + (r.x & tmask)) << 1) | (r.w >> 30 & 1u));
+        if (r.y != 0xFFFFFFFFu) c2 = ((u64)(r.y >> TILE_BITS) << 32) | (((t0 + (r.y & tmask)) << 1) | (r.w >> 31));
+        if (r.z != 0xFFFFFFFFu) c3 = ((u64)(r.z >> TILE_BITS) << 32) | 0xFFFFFFFFu;
     } else {
         for (int j = l; j < n_splits; j += 32) take(job.partial[(size_t)j * job.q_rows_alloc + q]);
         for (int off = 1; off < 32 && off < n_splits; off <<= 1) {
@@ -655,11 +661,11 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
 // 8 lanes share a row so that each load instruction fetches whole 128-B rows.
 constexpr int REDO_MAX_SEG = 64;
 
-__device__ __forceinline__ int redo_segments(const KnnJob& job, int n_redo, int n_splits)
+__device__ __forceinline__ int redo_segments(const KnnJob& job, int n_redo, int n_splits, int max_seg)
 {
     const long long cap = (long long)job.q_rows_alloc * n_splits;  // uint4 slots in job.partial
     long long nseg = n_redo > 0 ? cap / n_redo : 1;
-    if (nseg > REDO_MAX_SEG) nseg = REDO_MAX_SEG;
+    if (nseg > max_seg) nseg = max_seg;
     return nseg < 1 ? 1 : (int)nseg;
 }
 
@@ -673,13 +679,13 @@ __device__ __forceinline__ void merge2(u64& a1, u64& a2, u64 b1, u64 b2)
 }
 
 __global__ void __launch_bounds__(256)
-knn_redo_scan_kernel(const KnnJob* __restrict__ jobs, int n_splits)
+knn_redo_scan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int max_seg)
 {
     __shared__ u64 sh[2 * 4];
     const KnnJob job = jobs[blockIdx.y];
     const int n_redo = job.redo[0];
     if (n_redo == 0) return;
-    const int nseg = redo_segments(job, n_redo, n_splits);
+    const int nseg = redo_segments(job, n_redo, n_splits, max_seg);
     const int seg_rows = ((job.n_train + nseg - 1) / nseg + 31) & ~31;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sg = lane & 7, rsub = lane >> 3;
@@ -737,11 +743,11 @@ knn_redo_scan_kernel(const KnnJob* __restrict__ jobs, int n_splits)
 }
 
 __global__ void __launch_bounds__(256)
-knn_redo_merge_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k)
+knn_redo_merge_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int max_seg)
 {
     const KnnJob job = jobs[blockIdx.y];
     const int n_redo = job.redo[0];
-    const int nseg = redo_segments(job, n_redo, n_splits);
+    const int nseg = redo_segments(job, n_redo, n_splits, max_seg);
     const u64 NONE = ~0ull;
     for (int item = blockIdx.x * 256 + threadIdx.x; item < n_redo; item += gridDim.x * 256) {
         const int q = job.redo[1 + item];
@@ -871,8 +877,13 @@ hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs
 
 hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_splits, int k)
 {
-    hipLaunchKernelGGL(knn_redo_scan_kernel, dim3(512, n_jobs), dim3(256), 0, s, jobs_dev, n_splits);
-    hipLaunchKernelGGL(knn_redo_merge_kernel, dim3(4, n_jobs), dim3(256), 0, s, jobs_dev, n_splits, k);
+    // flagged queries are rare: about 2048 workgroups in all are plenty, and a
+    // larger grid only costs launch time
+    const int gx = std::min(512, std::max(8, 2048 / (n_jobs > 0 ? n_jobs : 1)));
+    // with many jobs in flight a flagged query is cut into fewer, longer segments
+    const int max_seg = std::min(REDO_MAX_SEG, std::max(1, 512 / (n_jobs > 0 ? n_jobs : 1)));
+    hipLaunchKernelGGL(knn_redo_scan_kernel, dim3(gx, n_jobs), dim3(256), 0, s, jobs_dev, n_splits, max_seg);
+    hipLaunchKernelGGL(knn_redo_merge_kernel, dim3(4, n_jobs), dim3(256), 0, s, jobs_dev, n_splits, k, max_seg);
     return hipGetLastError();
 }
 

@@ -1386,35 +1386,52 @@ __device__ __forceinline__ f2v max2(f2v a, f2v b)
     return r;
 }
 
-// Two points against one model: h_in <= 0 proves an inlier, h_out >= 0 an outlier.
+// Two points against one model.  Terms: squared residuals and denominators
+// (two sides for the symmetric epipolar distance, one for Sampson).
+struct PairTerms {
+    f2v n1, den1, n2, den2;
+};
 template <int MODEL>
-__device__ __forceinline__ void filter_pair(const float* Mf, const FilterConst& fc, f2v x1, f2v y1, f2v x2, f2v y2,
-                                            f2v& h_in, f2v& h_out)
+__device__ __forceinline__ PairTerms filter_terms(const float* Mf, f2v x1, f2v y1, f2v x2, f2v y2)
 {
+    PairTerms t;
     const f2v a = fma2(splat(Mf[0]), x1, fma2(splat(Mf[1]), y1, splat(Mf[2])));
     const f2v b = fma2(splat(Mf[3]), x1, fma2(splat(Mf[4]), y1, splat(Mf[5])));
     const f2v c = fma2(splat(Mf[6]), x1, fma2(splat(Mf[7]), y1, splat(Mf[8])));
     const f2v d2 = fma2(x2, a, fma2(y2, b, c));
     const f2v at = fma2(splat(Mf[0]), x2, fma2(splat(Mf[3]), y2, splat(Mf[6])));
     const f2v bt = fma2(splat(Mf[1]), x2, fma2(splat(Mf[4]), y2, splat(Mf[7])));
-    const f2v n2 = d2 * d2;
+    t.n2 = d2 * d2;
     if (MODEL == SFM_GPU_MODEL_FUNDAMENTAL) {
         const f2v ct = fma2(splat(Mf[2]), x2, fma2(splat(Mf[5]), y2, splat(Mf[8])));
         const f2v d1 = fma2(x1, at, fma2(y1, bt, ct));
-        const f2v n1 = d1 * d1;
-        const f2v den2 = fma2(a, a, b * b);
-        const f2v den1 = fma2(at, at, bt * bt);
-        const f2v hi1 = fma2(n1, splat(fc.c1), fma2(den1, splat(-fc.c2), splat(fc.kin[0])));
-        const f2v hi2 = fma2(n2, splat(fc.c1), fma2(den2, splat(-fc.c2), splat(fc.kin[1])));
-        const f2v ho1 = fma2(n1, splat(fc.c3), fma2(den1, splat(-fc.c4), splat(-fc.kout[0])));
-        const f2v ho2 = fma2(n2, splat(fc.c3), fma2(den2, splat(-fc.c4), splat(-fc.kout[1])));
-        h_in = max2(hi1, hi2);    // both sides must prove "in"
-        h_out = max2(ho1, ho2);   // either side may prove "out"
+        t.n1 = d1 * d1;
+        t.den2 = fma2(a, a, b * b);
+        t.den1 = fma2(at, at, bt * bt);
     } else {
-        const f2v den = fma2(a, a, fma2(b, b, fma2(at, at, bt * bt)));
-        h_in = fma2(n2, splat(fc.c1), fma2(den, splat(-fc.c2), splat(fc.kin[0])));
-        h_out = fma2(n2, splat(fc.c3), fma2(den, splat(-fc.c4), splat(-fc.kout[0])));
+        t.den2 = fma2(a, a, fma2(b, b, fma2(at, at, bt * bt)));
+        t.n1 = t.n2;
+        t.den1 = t.den2;
     }
+    return t;
+}
+// h_in <= 0 proves an inlier (both sides must prove it) ...
+template <int MODEL>
+__device__ __forceinline__ f2v filter_h_in(const PairTerms& t, const FilterConst& fc)
+{
+    const f2v h2 = fma2(t.n2, splat(fc.c1), fma2(t.den2, splat(-fc.c2), splat(fc.kin[1])));
+    if (MODEL != SFM_GPU_MODEL_FUNDAMENTAL) return h2;
+    const f2v h1 = fma2(t.n1, splat(fc.c1), fma2(t.den1, splat(-fc.c2), splat(fc.kin[0])));
+    return max2(h1, h2);
+}
+// ... h_out >= 0 an outlier (either side may prove it)
+template <int MODEL>
+__device__ __forceinline__ f2v filter_h_out(const PairTerms& t, const FilterConst& fc)
+{
+    const f2v h2 = fma2(t.n2, splat(fc.c3), fma2(t.den2, splat(-fc.c4), splat(-fc.kout[1])));
+    if (MODEL != SFM_GPU_MODEL_FUNDAMENTAL) return h2;
+    const f2v h1 = fma2(t.n1, splat(fc.c3), fma2(t.den1, splat(-fc.c4), splat(-fc.kout[0])));
+    return max2(h1, h2);
 }
 
 // Inlier counts: one thread per listed candidate model, which it keeps in
@@ -1494,18 +1511,22 @@ __global__ void __launch_bounds__(64) ransac_score_kernel(const RansacProb* __re
 #pragma unroll
             for (int k = 0; k < 8; ++k) cur[k] = nx[k];
             fetch(i + 4 < i4 ? i + 4 : i);  // the last step re-reads its own points
-            f2v hinA, houtA, hinB, houtB;
-            filter_pair<MODEL>(Mf, fc, cur[0], cur[2], cur[4], cur[6], hinA, houtA);
-            filter_pair<MODEL>(Mf, fc, cur[1], cur[3], cur[5], cur[7], hinB, houtB);
+            const PairTerms tA = filter_terms<MODEL>(Mf, cur[0], cur[2], cur[4], cur[6]);
+            const PairTerms tB = filter_terms<MODEL>(Mf, cur[1], cur[3], cur[5], cur[7]);
+            const f2v hinA = filter_h_in<MODEL>(tA, fc), hinB = filter_h_in<MODEL>(tB, fc);
             const bool in0 = hinA.x <= 0.f, in1 = hinA.y <= 0.f, in2 = hinB.x <= 0.f, in3 = hinB.y <= 0.f;
             cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0) + (in2 ? 1 : 0) + (in3 ? 1 : 0);
-            const bool u0 = !(in0 || houtA.x >= 0.f), u1 = !(in1 || houtA.y >= 0.f);
-            const bool u2 = !(in2 || houtB.x >= 0.f), u3 = !(in3 || houtB.y >= 0.f);
-            if (u0 || u1 || u2 || u3) {
-                if (u0) park(i);
-                if (u1) park(i + 1);
-                if (u2) park(i + 2);
-                if (u3) park(i + 3);
+            // the outlier test is only needed where a lane could not prove "in"
+            if (__builtin_amdgcn_ballot_w64(!(in0 && in1 && in2 && in3)) != 0ull) {
+                const f2v houtA = filter_h_out<MODEL>(tA, fc), houtB = filter_h_out<MODEL>(tB, fc);
+                const bool u0 = !(in0 || houtA.x >= 0.f), u1 = !(in1 || houtA.y >= 0.f);
+                const bool u2 = !(in2 || houtB.x >= 0.f), u3 = !(in3 || houtB.y >= 0.f);
+                if (u0 || u1 || u2 || u3) {
+                    if (u0) park(i);
+                    if (u1) park(i + 1);
+                    if (u2) park(i + 2);
+                    if (u3) park(i + 3);
+                }
             }
         }
     }
