@@ -699,26 +699,36 @@ knn_redo_scan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int max_seg)
         const int qn = job.q_qn[q];
         u64 f = NONE, s = NONE;
         int d2f = 0x7FFFFFFF, lim = 0x7FFFFFFF;  // d2 of this lane's best / second best so far
-        for (int base = r0 + wave * 8; base < r1; base += 4 * 8) {
-            const int row = base + rsub;
-            const bool ok = row < r1;
-            const int rr = ok ? row : 0;
-            const v4i tv = *(const v4i*)(job.t_desc + (size_t)rr * DIM + sg * 16);
-            const int tn = job.t_qn[rr];
-            int acc = __builtin_amdgcn_sdot4(qv[0], tv[0], 0, false);
-            acc = __builtin_amdgcn_sdot4(qv[1], tv[1], acc, false);
-            acc = __builtin_amdgcn_sdot4(qv[2], tv[2], acc, false);
-            acc = __builtin_amdgcn_sdot4(qv[3], tv[3], acc, false);
-            acc += __shfl_xor(acc, 1);
-            acc += __shfl_xor(acc, 2);
-            acc += __shfl_xor(acc, 4);
-            const int d2 = qn + tn - 2 * acc;
-            // rows come in ascending order, so a later row needs a float distance
-            // strictly below the second best's, hence a smaller d2
-            if (ok && sg == 0 && d2 < lim) {
-                const u64 key = ((u64)__float_as_uint(sqrt_exact_u32((uint32_t)d2)) << 32) | (uint32_t)row;
-                if (key < f) { s = f; f = key; lim = d2f; d2f = d2; }
-                else if (key < s) { s = key; lim = d2; }
+        // four row groups per step, their loads issued together
+        for (int base = r0 + wave * 8; base < r1; base += 4 * 4 * 8) {
+            v4i tv[4];
+            int tn[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = base + g * 32 + rsub;
+                const int rr = row < r1 ? row : 0;
+                tv[g] = *(const v4i*)(job.t_desc + (size_t)rr * DIM + sg * 16);
+                tn[g] = job.t_qn[rr];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = base + g * 32 + rsub;
+                const bool ok = row < r1;
+                int acc = __builtin_amdgcn_sdot4(qv[0], tv[g][0], 0, false);
+                acc = __builtin_amdgcn_sdot4(qv[1], tv[g][1], acc, false);
+                acc = __builtin_amdgcn_sdot4(qv[2], tv[g][2], acc, false);
+                acc = __builtin_amdgcn_sdot4(qv[3], tv[g][3], acc, false);
+                acc += __shfl_xor(acc, 1);
+                acc += __shfl_xor(acc, 2);
+                acc += __shfl_xor(acc, 4);
+                const int d2 = qn + tn[g] - 2 * acc;
+                // rows come in ascending order, so a later row needs a float distance
+                // strictly below the second best's, hence a smaller d2
+                if (ok && sg == 0 && d2 < lim) {
+                    const u64 key = ((u64)__float_as_uint(sqrt_exact_u32((uint32_t)d2)) << 32) | (uint32_t)row;
+                    if (key < f) { s = f; f = key; lim = d2f; d2f = d2; }
+                    else if (key < s) { s = key; lim = d2; }
+                }
             }
         }
 #pragma unroll

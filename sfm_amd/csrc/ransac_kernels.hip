@@ -1319,7 +1319,7 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 
 struct FilterConst {
     float c1, c2, c3, c4;  // multipliers of d^2 and den in the two tests
-    float kin[2], kout[2]; // additive terms per side (side 1 only for Sampson)
+    float kin[2], kout[2]; // additive terms ([0] is used; [1] mirrors it)
 };
 
 __device__ __forceinline__ float f_up(double v) { return (float)(v * (1.0 + 1.0 / 1048576.0)); }
@@ -1341,13 +1341,19 @@ __device__ __forceinline__ FilterConst make_filter(const double* M, double R, fl
     // columns against (x2,y2,1)
     const double q0 = (m[0] + m[3]) * Rr + m[6], q1 = (m[1] + m[4]) * Rr + m[7], q2 = (m[2] + m[5]) * Rr + m[8];
     if (MODEL == SFM_GPU_MODEL_FUNDAMENTAL) {
-        const double s2 = Rr * (r0 + r1) + r2;  // residual of side 2 (rows, then x2)
-        const double s1 = Rr * (q0 + q1) + q2;  // residual of side 1 (columns, then x1)
-        kn[0] = (16 * u * s1) * (16 * u * s1) * ke;
-        kd[0] = ((8 * u * q0) * (8 * u * q0) + (8 * u * q1) * (8 * u * q1)) * ke;
-        kn[1] = (16 * u * s2) * (16 * u * s2) * ke;
-        kd[1] = ((8 * u * r0) * (8 * u * r0) + (8 * u * r1) * (8 * u * r1)) * ke;
-        smax = fmax(fmax(s1, s2), fmax(fmax(r0, r1), fmax(q0, q1)));
+        // The two residuals x2^T F x1 and x1^T F^T x2 are one real number; their
+        // double-precision values differ from it by rounding only (2^-50 of the
+        // term sums), so the filter evaluates it once and tests it against the
+        // smaller of the two denominators with the larger of the two slacks.
+        const double s2 = Rr * (r0 + r1) + r2;  // term sum of x2^T (F x1)
+        const double s1 = Rr * (q0 + q1) + q2;  // term sum of x1^T (F^T x2)
+        const double sm = fmax(s1, s2) * (1.0 + 1.0 / 1048576.0);
+        kn[0] = (16 * u * sm) * (16 * u * sm) * ke;
+        kd[0] = fmax((8 * u * q0) * (8 * u * q0) + (8 * u * q1) * (8 * u * q1),
+                     (8 * u * r0) * (8 * u * r0) + (8 * u * r1) * (8 * u * r1)) * ke;
+        kn[1] = kn[0];
+        kd[1] = kd[0];
+        smax = fmax(sm, fmax(fmax(r0, r1), fmax(q0, q1)));
     } else {
         const double ss = Rr * (r0 + r1) + r2;
         kn[0] = (16 * u * ss) * (16 * u * ss) * ke;
@@ -1386,11 +1392,18 @@ __device__ __forceinline__ f2v max2(f2v a, f2v b)
     return r;
 }
 
-// Two points against one model.  Terms: squared residuals and denominators
-// (two sides for the symmetric epipolar distance, one for Sampson).
+// Two points against one model: squared residual and the denominator to test
+// it against (the smaller of the two sides for the symmetric epipolar distance).
 struct PairTerms {
-    f2v n1, den1, n2, den2;
+    f2v n, den;
 };
+__device__ __forceinline__ f2v min2(f2v a, f2v b)
+{
+    f2v r;
+    r.x = fminf(a.x, b.x);
+    r.y = fminf(a.y, b.y);
+    return r;
+}
 template <int MODEL>
 __device__ __forceinline__ PairTerms filter_terms(const float* Mf, f2v x1, f2v y1, f2v x2, f2v y2)
 {
@@ -1398,40 +1411,22 @@ __device__ __forceinline__ PairTerms filter_terms(const float* Mf, f2v x1, f2v y
     const f2v a = fma2(splat(Mf[0]), x1, fma2(splat(Mf[1]), y1, splat(Mf[2])));
     const f2v b = fma2(splat(Mf[3]), x1, fma2(splat(Mf[4]), y1, splat(Mf[5])));
     const f2v c = fma2(splat(Mf[6]), x1, fma2(splat(Mf[7]), y1, splat(Mf[8])));
-    const f2v d2 = fma2(x2, a, fma2(y2, b, c));
+    const f2v d = fma2(x2, a, fma2(y2, b, c));
     const f2v at = fma2(splat(Mf[0]), x2, fma2(splat(Mf[3]), y2, splat(Mf[6])));
     const f2v bt = fma2(splat(Mf[1]), x2, fma2(splat(Mf[4]), y2, splat(Mf[7])));
-    t.n2 = d2 * d2;
-    if (MODEL == SFM_GPU_MODEL_FUNDAMENTAL) {
-        const f2v ct = fma2(splat(Mf[2]), x2, fma2(splat(Mf[5]), y2, splat(Mf[8])));
-        const f2v d1 = fma2(x1, at, fma2(y1, bt, ct));
-        t.n1 = d1 * d1;
-        t.den2 = fma2(a, a, b * b);
-        t.den1 = fma2(at, at, bt * bt);
-    } else {
-        t.den2 = fma2(a, a, fma2(b, b, fma2(at, at, bt * bt)));
-        t.n1 = t.n2;
-        t.den1 = t.den2;
-    }
+    t.n = d * d;
+    if (MODEL == SFM_GPU_MODEL_FUNDAMENTAL) t.den = min2(fma2(a, a, b * b), fma2(at, at, bt * bt));
+    else t.den = fma2(a, a, fma2(b, b, fma2(at, at, bt * bt)));
     return t;
 }
-// h_in <= 0 proves an inlier (both sides must prove it) ...
-template <int MODEL>
+// h_in <= 0 proves an inlier, h_out >= 0 an outlier
 __device__ __forceinline__ f2v filter_h_in(const PairTerms& t, const FilterConst& fc)
 {
-    const f2v h2 = fma2(t.n2, splat(fc.c1), fma2(t.den2, splat(-fc.c2), splat(fc.kin[1])));
-    if (MODEL != SFM_GPU_MODEL_FUNDAMENTAL) return h2;
-    const f2v h1 = fma2(t.n1, splat(fc.c1), fma2(t.den1, splat(-fc.c2), splat(fc.kin[0])));
-    return max2(h1, h2);
+    return fma2(t.n, splat(fc.c1), fma2(t.den, splat(-fc.c2), splat(fc.kin[0])));
 }
-// ... h_out >= 0 an outlier (either side may prove it)
-template <int MODEL>
 __device__ __forceinline__ f2v filter_h_out(const PairTerms& t, const FilterConst& fc)
 {
-    const f2v h2 = fma2(t.n2, splat(fc.c3), fma2(t.den2, splat(-fc.c4), splat(-fc.kout[1])));
-    if (MODEL != SFM_GPU_MODEL_FUNDAMENTAL) return h2;
-    const f2v h1 = fma2(t.n1, splat(fc.c3), fma2(t.den1, splat(-fc.c4), splat(-fc.kout[0])));
-    return max2(h1, h2);
+    return fma2(t.n, splat(fc.c3), fma2(t.den, splat(-fc.c4), splat(-fc.kout[0])));
 }
 
 // Inlier counts: one thread per listed candidate model, which it keeps in
@@ -1513,12 +1508,12 @@ __global__ void __launch_bounds__(64) ransac_score_kernel(const RansacProb* __re
             fetch(i + 4 < i4 ? i + 4 : i);  // the last step re-reads its own points
             const PairTerms tA = filter_terms<MODEL>(Mf, cur[0], cur[2], cur[4], cur[6]);
             const PairTerms tB = filter_terms<MODEL>(Mf, cur[1], cur[3], cur[5], cur[7]);
-            const f2v hinA = filter_h_in<MODEL>(tA, fc), hinB = filter_h_in<MODEL>(tB, fc);
+            const f2v hinA = filter_h_in(tA, fc), hinB = filter_h_in(tB, fc);
             const bool in0 = hinA.x <= 0.f, in1 = hinA.y <= 0.f, in2 = hinB.x <= 0.f, in3 = hinB.y <= 0.f;
             cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0) + (in2 ? 1 : 0) + (in3 ? 1 : 0);
             // the outlier test is only needed where a lane could not prove "in"
             if (__builtin_amdgcn_ballot_w64(!(in0 && in1 && in2 && in3)) != 0ull) {
-                const f2v houtA = filter_h_out<MODEL>(tA, fc), houtB = filter_h_out<MODEL>(tB, fc);
+                const f2v houtA = filter_h_out(tA, fc), houtB = filter_h_out(tB, fc);
                 const bool u0 = !(in0 || houtA.x >= 0.f), u1 = !(in1 || houtA.y >= 0.f);
                 const bool u2 = !(in2 || houtB.x >= 0.f), u3 = !(in3 || houtB.y >= 0.f);
                 if (u0 || u1 || u2 || u3) {
