@@ -556,14 +556,17 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
     const uint32_t id_lo = (!have_b || ida < idb) ? ida : idb;
     const uint32_t id_hi = (!have_b || ida < idb) ? idb : ida;
     const bool same_tile = have_b && (id_lo >> 1) == (id_hi >> 1);
-    // candidate position 0..31 -> train row (ascending), -1 when there is none
+    // candidate position 0..31 -> train row (ascending), -1 when there is none;
+    // written without branches (selects only)
+    const int tile_lo = (int)(id_lo >> 1) * 32, tile_hi = (int)(id_hi >> 1) * 32;
+    const int half_lo = 4 * (int)(id_lo & 1), half_hi = 4 * (int)(id_hi & 1);
     auto row_of = [&](int pos) -> int {
-        if (!have_a) return -1;
-        if (same_tile) return (int)(id_lo >> 1) * 32 + pos;  // both halves of one tile
-        if (pos >= 16 && !have_b) return -1;
-        const uint32_t id = pos < 16 ? id_lo : id_hi;
         const int i = pos & 15;
-        return (int)(id >> 1) * 32 + 8 * (i >> 2) + 4 * (int)(id & 1) + (i & 3);
+        const bool hi = pos >= 16;
+        const int split_row = (hi ? tile_hi + half_hi : tile_lo + half_lo) + 8 * (i >> 2) + (i & 3);
+        const int r = same_tile ? tile_lo + pos : split_row;
+        const bool none = !have_a || (hi && !have_b);
+        return none ? -1 : r;
     };
     // Dot products, 8 lanes per row so that each load instruction fetches whole
     // 128-B rows: lane l works on 16-byte segment l&7 of candidates 4*it + (l>>3).
@@ -577,11 +580,16 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
     const int qn = job.q_qn[q];
     const int tn = job.t_qn[row_ok ? row : 0];
     const v4i qv = *(const v4i*)(job.q_desc + (size_t)q * DIM + sg * 16);
+    // rows of candidates 4*it + rq: position 4*it + rq is in the low group for
+    // it < 4 (i = 4*it + rq, so i>>2 = it, i&3 = rq) and in the high one after
+    const int base_lo = have_a ? tile_lo + half_lo + rq : 0;
+    const int base_hi = have_b ? tile_hi + half_hi + rq : 0;
+    const int base_same = tile_lo + rq;
     v4i tv[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-        const int r = row_of(it * 4 + rq);
-        tv[it] = *(const v4i*)(job.t_desc + (size_t)(r < 0 ? 0 : r) * DIM + sg * 16);
+        const int r = same_tile ? base_same + 4 * it : (it < 4 ? base_lo : base_hi) + 8 * (it & 3);
+        tv[it] = *(const v4i*)(job.t_desc + (size_t)r * DIM + sg * 16);
     }
     int part[8];
 #pragma unroll
