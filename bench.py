@@ -146,6 +146,17 @@ def main():
         ms, cnt = ctx.profile_query(name)
         if cnt:
             kern[name] = {"avg_us": round(ms / cnt * 1e3, 2), "launches": cnt}
+    # ceiling on this box: the same sweep with its MFMAs and LDS fragment reads
+    # only (no digest, no DMA, no barrier; results are garbage and unused)
+    ctx.profile_select("knn2_mfma")
+    ctx.profile_reset()
+    ctx._L.sfm_gpu_debug_set_knn_variant(ctx.handle, 0 + 16 * 4)
+    for _ in range(3):
+        step()
+    ctx.synchronize()
+    ceil_ms, ceil_cnt = ctx.profile_query("knn2_mfma")
+    ctx._L.sfm_gpu_debug_set_knn_variant(ctx.handle, -1)
+    ctx.profile_select(None)
     ctx.profile_enable(False)
 
     if world > 1:
@@ -200,6 +211,12 @@ def main():
                 "traffic": traffic,
                 "ops_per_launch": ops_per_launch,
                 "avg_launch_us": knn["avg_us"],
+                "mfma_only_microkernel": {
+                    "what": "same launch with MFMAs + LDS fragment reads only, measured after the timed region",
+                    "avg_launch_us": round(ceil_ms / max(ceil_cnt, 1) * 1e3, 2),
+                    "frac_of_peak": round(ops_per_launch / (ceil_ms / max(ceil_cnt, 1) * 1e-3) / 1e12
+                                          / INT8_DENSE_PEAK_TOPS, 4) if ceil_cnt else None,
+                },
             },
             "kernels_outside_timed_region": kern,
         }

@@ -205,10 +205,23 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, done_rows, b));
         }
         counts.resize((size_t)n_prob * b * 10);
-        for (int p = 0; p < n_prob; ++p) {
-            if (st[p].done) continue;
-            SFM_HIP(ctx, hipMemcpyAsync(&counts[(size_t)p * b * 10], probs[p].counts + (size_t)done_rows * 10,
-                                        (size_t)b * 40, hipMemcpyDeviceToHost, s));
+        // the problems' workspaces are carved at a constant stride: one strided copy
+        // brings every problem's slice of counts
+        bool uniform = n_prob > 1;
+        const ptrdiff_t stride = n_prob > 1 ? (const char*)probs[1].counts - (const char*)probs[0].counts : 0;
+        for (int p = 1; p < n_prob && uniform; ++p)
+            uniform = (const char*)probs[p].counts - (const char*)probs[p - 1].counts == stride && stride > 0;
+        if (uniform) {
+            SFM_HIP(ctx, hipMemcpy2DAsync(counts.data(), (size_t)b * 40, probs[0].counts + (size_t)done_rows * 10,
+                                          (size_t)stride, (size_t)b * 40, (size_t)n_prob, hipMemcpyDeviceToHost,
+                                          s));
+        } else {
+            for (int p = 0; p < n_prob; ++p) {
+                if (st[p].done) continue;
+                SFM_HIP(ctx, hipMemcpyAsync(&counts[(size_t)p * b * 10],
+                                            probs[p].counts + (size_t)done_rows * 10, (size_t)b * 40,
+                                            hipMemcpyDeviceToHost, s));
+            }
         }
         rc = fetch_results();
         if (rc) return rc;

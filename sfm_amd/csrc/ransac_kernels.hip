@@ -983,6 +983,20 @@ __device__ bool subset_collinear(const RansacProb& pb, const int* idx, int m)
     return have_collinear(a, m) || have_collinear(b, m);
 }
 
+// The same check for a seven-point subset with every gather issued up front.
+__device__ bool subset_collinear7(const RansacProb& pb, const int* idx)
+{
+    float a[14], b[14];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const float2 u = ((const float2*)pb.f1)[idx[k]];
+        const float2 v = ((const float2*)pb.f2)[idx[k]];
+        a[2 * k] = u.x; a[2 * k + 1] = u.y;
+        b[2 * k] = v.x; b[2 * k + 1] = v.y;
+    }
+    return have_collinear(a, 7) || have_collinear(b, 7);
+}
+
 // Fixed-count mode: rows are independent draws of a counter-based generator
 // (splitmix64 finaliser over row / subset attempt / slot / slot attempt), one
 // thread per row.  No OpenCV counterpart; the adaptive mode below keeps
@@ -1040,55 +1054,97 @@ __global__ void __launch_bounds__(256) ransac_table_fixed_kernel(const RansacPro
 
 // Sample table rows [row0, row0+nrows): m distinct uniform draws per row from
 // the cv::RNG stream seeded with 2^64-1, whole-subset redraw when the
-// fundamental-matrix collinearity check rejects it (at most 10000 attempts).
-// The stream is strictly sequential: one lane per problem; the generator
-// state is parked in the result block between calls.
+// fundamental-matrix collinearity check rejects it (a row fails after 10000
+// rejections in a row).  The stream of candidate subsets does not depend on
+// which of them are accepted, so lane 0 draws a run of candidates (pure
+// arithmetic), all lanes check one candidate each, and the accepted ones are
+// taken in stream order.  The generator state after the last candidate used is
+// parked in the result block between calls.
 __global__ void __launch_bounds__(64) ransac_table_kernel(const RansacProb* __restrict__ probs, int row0, int nrows)
 {
-    if (threadIdx.x != 0) return;
+    __shared__ int cand[64][8];
+    __shared__ unsigned long long st_after[64];
     const RansacProb pb = probs[blockIdx.x];
+    const int lane = threadIdx.x;
     const int n = *pb.n_ptr;
     const int m = pb.m;
     if (n < m) return;
     if (row0 > 0 && pb.result[R_VALID] < row0) return;  // stream ended earlier
     if (n == m) {
-        if (row0 == 0) {
+        if (row0 == 0 && lane == 0) {
             for (int i = 0; i < m; ++i) pb.table[i] = i;
             pb.result[R_VALID] = 1;
             pb.result[R_DIRECT] = 1;
         }
         return;
     }
-    CvRng rng;
-    if (row0 == 0) rng.state = ~0ull;
-    else rng.state = ((unsigned long long)(unsigned)pb.result[R_RNG_HI] << 32) | (unsigned)pb.result[R_RNG_LO];
+    unsigned long long state;
+    if (row0 == 0) state = ~0ull;
+    else state = ((unsigned long long)(unsigned)pb.result[R_RNG_HI] << 32) | (unsigned)pb.result[R_RNG_LO];
     const bool check = pb.model == SFM_GPU_MODEL_FUNDAMENTAL;
+    // x % n for 32-bit x without a division: r = hi64((M * x) * n), M = floor((2^64-1)/n) + 1
+    const unsigned long long magic = 0xFFFFFFFFFFFFFFFFull / (unsigned)n + 1ull;
+    const int end = row0 + nrows;
     int valid = row0;
-    for (int r = row0; r < row0 + nrows; ++r) {
-        int idx[7];
-        int iters = 0, i = 0;
-        for (; iters < 10000; ++iters) {
-            for (i = 0; i < m && iters < 10000;) {
-                int v;
-                for (;;) {
-                    v = idx[i] = rng.uniform(0, n);
-                    int j = 0;
-                    for (; j < i; ++j)
-                        if (v == idx[j]) break;
-                    if (j == i) break;
+    int rejects = 0;  // consecutive rejected candidates for the row being filled
+    bool failed = false;
+    while (valid < end && !failed) {
+        const int chunk = min(64, end - valid);
+        if (lane == 0) {
+            CvRng rng;
+            rng.state = state;
+            for (int c = 0; c < chunk; ++c) {
+                int idx[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    if (i < m) {
+                        int v;
+                        for (;;) {
+                            const unsigned x = rng.next();
+                            v = (int)__umul64hi(magic * x, (unsigned long long)(unsigned)n);
+                            bool dup = false;
+#pragma unroll
+                            for (int j = 0; j < i; ++j) dup |= (idx[j] == v);
+                            if (!dup) break;
+                        }
+                        idx[i] = v;
+                        cand[c][i] = v;
+                    }
                 }
-                ++i;
+                st_after[c] = rng.state;
             }
-            if (i == m && check && subset_collinear(pb, idx, m)) continue;
-            break;
         }
-        if (!(i == m && iters < 10000)) break;
-        for (int k = 0; k < m; ++k) pb.table[(size_t)r * m + k] = idx[k];
-        valid = r + 1;
+        __syncthreads();
+        bool rej = false;
+        if (check && lane < chunk) {
+            int idx[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) idx[i] = cand[lane][i];
+            rej = subset_collinear7(pb, idx);
+        }
+        const unsigned long long rejmask = __builtin_amdgcn_ballot_w64(rej);
+        int last = -1;
+        for (int c = 0; c < chunk && valid < end; ++c) {
+            last = c;
+            if ((rejmask >> c) & 1ull) {
+                if (++rejects >= 10000) {
+                    failed = true;
+                    break;
+                }
+            } else {
+                if (lane < m) pb.table[(size_t)valid * m + lane] = cand[c][lane];
+                ++valid;
+                rejects = 0;
+            }
+        }
+        state = st_after[last];
+        __syncthreads();
     }
-    pb.result[R_VALID] = valid;
-    pb.result[R_RNG_HI] = (int)(unsigned)(rng.state >> 32);
-    pb.result[R_RNG_LO] = (int)(unsigned)rng.state;
+    if (lane == 0) {
+        pb.result[R_VALID] = valid;
+        pb.result[R_RNG_HI] = (int)(unsigned)(state >> 32);
+        pb.result[R_RNG_LO] = (int)(unsigned)state;
+    }
 }
 
 // One wavefront per hypothesis.
