@@ -128,9 +128,11 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
     results.assign((size_t)n_prob * R_COUNT, 0);
     // the result blocks of a batch are contiguous (probs[p].result = base + p * R_COUNT)
     auto fetch_results = [&]() -> int {
-        SFM_HIP(ctx, hipMemcpyAsync(results.data(), probs[0].result, (size_t)n_prob * R_COUNT * 4,
-                                    hipMemcpyDeviceToHost, s));
+        const size_t bytes = (size_t)n_prob * R_COUNT * 4;
+        SFM_HIP(ctx, ctx->pin_a.reserve(bytes));
+        SFM_HIP(ctx, hipMemcpyAsync(ctx->pin_a.p, probs[0].result, bytes, hipMemcpyDeviceToHost, s));
         SFM_HIP(ctx, hipStreamSynchronize(s));
+        std::memcpy(results.data(), ctx->pin_a.p, bytes);
         return SFM_GPU_OK;
     };
 
@@ -211,20 +213,23 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         const ptrdiff_t stride = n_prob > 1 ? (const char*)probs[1].counts - (const char*)probs[0].counts : 0;
         for (int p = 1; p < n_prob && uniform; ++p)
             uniform = (const char*)probs[p].counts - (const char*)probs[p - 1].counts == stride && stride > 0;
+        SFM_HIP(ctx, ctx->pin_b.reserve(counts.size() * 4));
+        int32_t* counts_pin = ctx->pin_b.as<int32_t>();
         if (uniform) {
-            SFM_HIP(ctx, hipMemcpy2DAsync(counts.data(), (size_t)b * 40, probs[0].counts + (size_t)done_rows * 10,
+            SFM_HIP(ctx, hipMemcpy2DAsync(counts_pin, (size_t)b * 40, probs[0].counts + (size_t)done_rows * 10,
                                           (size_t)stride, (size_t)b * 40, (size_t)n_prob, hipMemcpyDeviceToHost,
                                           s));
         } else {
             for (int p = 0; p < n_prob; ++p) {
                 if (st[p].done) continue;
-                SFM_HIP(ctx, hipMemcpyAsync(&counts[(size_t)p * b * 10],
+                SFM_HIP(ctx, hipMemcpyAsync(&counts_pin[(size_t)p * b * 10],
                                             probs[p].counts + (size_t)done_rows * 10, (size_t)b * 40,
                                             hipMemcpyDeviceToHost, s));
             }
         }
         rc = fetch_results();
         if (rc) return rc;
+        std::memcpy(counts.data(), counts_pin, counts.size() * 4);
         for (int p = 0; p < n_prob; ++p) {
             St& t = st[p];
             if (t.done) continue;
@@ -521,8 +526,10 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
             ProfScope ps(ctx, "inlier_compact");
             SFM_HIP(ctx, launch_inlier_compact(s, dpds, g));
         }
-        SFM_HIP(ctx, hipMemcpyAsync(ng.data(), ctx->mp_ngood.p, 8 * (size_t)g, hipMemcpyDeviceToHost, s));
+        SFM_HIP(ctx, ctx->pin_a.reserve(8 * (size_t)g));
+        SFM_HIP(ctx, hipMemcpyAsync(ctx->pin_a.p, ctx->mp_ngood.p, 8 * (size_t)g, hipMemcpyDeviceToHost, s));
         SFM_HIP(ctx, hipStreamSynchronize(s));
+        std::memcpy(ng.data(), ctx->pin_a.p, 8 * (size_t)g);
         for (int i = 0; i < g; ++i) {
             n_good[g0 + i] = ng[2 * i];
             n_inliers[g0 + i] = ng[2 * i + 1];

@@ -39,6 +39,32 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+// Pinned host staging memory (grow-only): small device-to-host copies into
+// pageable memory are staged by the runtime and cost far more than the copy.
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return (T*)p; }
+};
+
 // Bytes of the device block that holds an image of n rows:
 // [desc rows*128 | cin rows*4 | qn rows*4 | keypoints rows*8].
 inline int image_rows_alloc(int n) { return ((n > 0 ? n : 1) + ROW_ALIGN - 1) / ROW_ALIGN * ROW_ALIGN; }
@@ -102,6 +128,7 @@ struct sfm_gpu_ctx {
     sfm::DevBuf partial, out, counts, redo, jobs, flags, prepjobs;
     // ransac workspaces
     sfm::DevBuf rs_pts, rs_table, rs_models, rs_counts, rs_mask, rs_misc;
+    sfm::PinnedBuf pin_a, pin_b;  // host staging for results / counts / descriptors of jobs
     // match_pairs workspaces
     sfm::DevBuf mp_good, mp_pts, mp_ngood;
 

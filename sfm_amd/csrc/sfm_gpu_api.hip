@@ -175,6 +175,8 @@ void sfm_gpu_destroy(sfm_gpu_ctx* c)
     for (DevBuf* b : bufs) b->release();
     c->tmp_q.release();
     c->tmp_t.release();
+    c->pin_a.release();
+    c->pin_b.release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
