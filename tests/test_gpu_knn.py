@@ -163,3 +163,56 @@ def test_knn_32k_self_match_property(gpu_ctx):
     assert same.mean() > 0.999
     assert (gm["distance"][:, 1] >= gm["distance"][:, 0]).all()
     assert (gc == 2).all()
+
+
+def _numpy_top2(Q, T, rows):
+    """Exact top-2 of the given query rows by integer arithmetic in numpy:
+    (trainIdx[2], float32 distance[2]) with OpenCV's order (float distance, then
+    ascending train index)."""
+    Ti = T.astype(np.int64)
+    out_idx, out_d = [], []
+    for r in rows:
+        d2 = ((Ti - Q[r].astype(np.int64)) ** 2).sum(1)
+        d = np.sqrt(d2.astype(np.float64)).astype(np.float32)   # d2 < 2^24: sqrt correctly rounded via double
+        order = np.lexsort((np.arange(len(T)), d))[:2]
+        out_idx.append(order)
+        out_d.append(d[order])
+    return np.array(out_idx), np.array(out_d)
+
+
+@pytest.mark.parametrize("nq,nt,seed", [(20000, 20000, 1201), (32768, 32768, 1202), (9001, 30011, 1203)])
+def test_knn_large_ragged_sizes_against_numpy_sample(gpu_ctx, nq, nt, seed):
+    # sizes of the larger configurations (20k x 20k views, 32k x 32k pair, a ragged
+    # pair): a random sample of query rows is checked against an independent exact
+    # computation, which does not depend on the size the CPU oracle can finish
+    Q, T, _ = synth.planted_pair(nq, nt, seed, seed + 1, seed + 2)
+    gm, gc = matcher.BFMatcher(gpu_ctx).knnMatch(Q, T, 2)
+    assert (gc == 2).all() and (gm["queryIdx"][:, 0] == np.arange(nq)).all()
+    rows = np.random.default_rng(seed).choice(nq, 96, replace=False)
+    idx, dist = _numpy_top2(Q, T, rows)
+    assert (gm["trainIdx"][rows] == idx).all()
+    assert (gm["distance"][rows].view(np.uint32) == dist.view(np.uint32)).all()
+    assert (gm["distance"][:, 1] >= gm["distance"][:, 0]).all()
+
+
+def test_knn_argument_errors_and_limits(gpu_ctx):
+    from sfm_amd import _lib
+    bf = matcher.BFMatcher(gpu_ctx)
+    q = np.zeros((4, 128), np.float32)
+    with pytest.raises(_lib.SfmGpuError) as e:
+        bf.knnMatch(q, q, 3)                       # k > 2 is not on the path
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    with pytest.raises(_lib.SfmGpuError) as e:
+        bf.knnMatch(np.zeros((4, 64), np.float32), np.zeros((4, 64), np.float32), 2)   # dim != 128
+    assert e.value.code == _lib.ERR_ARG
+    with pytest.raises(_lib.SfmGpuError) as e:       # cv::BFMatcher's own limit on the train set
+        bf.knnMatch(np.zeros((1, 128), np.uint8), np.zeros((1 << 18, 128), np.uint8), 2)
+    assert e.value.code == _lib.ERR_TOO_MANY
+    # the largest train set that is allowed: distances of an all-zero query to rows
+    # that are zero except one marked row
+    T = np.zeros(((1 << 18) - 1, 128), np.uint8)
+    T[:, 0] = 9
+    T[200001, 0] = 1
+    T[77, 0] = 2
+    gm, gc = bf.knnMatch(np.zeros((3, 128), np.uint8), T, 2)
+    assert (gm["trainIdx"] == [200001, 77]).all() and (gm["distance"] == [1.0, 2.0]).all()
