@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--hyps", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microkernel", action="store_true", help="skip the MFMA-only ceiling launches")
+    ap.add_argument("--knn-variant", type=int, default=-1, help="debug: force the sweep kernel shape")
     ap.add_argument("--score-filter", type=int, default=1, help="debug: 0 = double precision only")
     args = ap.parse_args()
 
@@ -104,6 +105,8 @@ def main():
         d_packed = torch.empty((2 * B, blk), dtype=torch.uint8, device="cuda")
     stream.synchronize()
     ctx = matcher.Context(local_rank, stream=stream.cuda_stream)
+    if args.knn_variant >= 0:
+        ctx._L.sfm_gpu_debug_set_knn_variant(ctx.handle, args.knn_variant)
     if args.score_filter != 1:
         ctx._L.sfm_gpu_debug_set_score_filter(args.score_filter)
     desc_ptrs = [d_desc[i].data_ptr() for i in range(2 * B)]
@@ -158,12 +161,12 @@ def main():
     # only (no digest, no DMA, no barrier; results are garbage and unused)
     ctx.profile_select("knn2_mfma")
     ctx.profile_reset()
-    ctx._L.sfm_gpu_debug_set_knn_variant(ctx.handle, 0 + 16 * 4)
+    ctx._L.sfm_gpu_debug_set_knn_variant(ctx.handle, (args.knn_variant if args.knn_variant >= 0 else 4) + 16 * 4)
     for _ in range(0 if args.no_microkernel else 3):
         step()
     ctx.synchronize()
     ceil_ms, ceil_cnt = ctx.profile_query("knn2_mfma")
-    ctx._L.sfm_gpu_debug_set_knn_variant(ctx.handle, -1)
+    ctx._L.sfm_gpu_debug_set_knn_variant(ctx.handle, args.knn_variant)
     ctx.profile_select(None)
     ctx.profile_enable(False)
 

@@ -12,7 +12,9 @@
 extern "C" {
 #endif
 
-/* Forces the workgroup shape of the distance kernel (-1: planner decides). */
+/* Forces the shape of the distance kernel (-1: planner decides): 0..3 = 32x32x32
+ * MFMAs with {4x4, 2x4, 2x8, 4x8} {query blocks per wave x waves}, 4 = 16x16x64
+ * MFMAs; + 16*a selects a timing ablation a (wrong results). */
 int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* ctx, int variant);
 
 /* Number of queries that the last k-NN call on this context (its first job)
@@ -23,6 +25,11 @@ int sfm_gpu_debug_redo_count(sfm_gpu_ctx* ctx, int32_t* out);
  * host pointers, through one v_mfma_i32_32x32x32_i8 loaded the way the
  * distance kernel loads its operands. */
 int sfm_gpu_debug_mfma_probe(sfm_gpu_ctx* ctx, const int8_t* a, const int8_t* b, int32_t* c);
+
+/* c[16][16] (int32) = a[16][64] * b^T with b given as [16 columns][64 k], through
+ * one v_mfma_i32_16x16x64_i8 loaded the way the 16x16 form of the distance kernel
+ * loads its operands. */
+int sfm_gpu_debug_mfma16_probe(sfm_gpu_ctx* ctx, const int8_t* a, const int8_t* b, int32_t* c);
 
 /* Per-hypothesis data of the last sfm_gpu_ransac call on this context: the
  * sample table [n_hyp][m], the number of candidate models per hypothesis, the

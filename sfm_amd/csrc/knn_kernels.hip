@@ -432,7 +432,7 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
     // Lanes l and l+32 hold the same query over disjoint groups: merge their
     // triples; lane l < 32 writes one record per (split, query):
     //   x = best group (x << 9 | tile), y = second group, z = third minimum,
-    //   w = first tile of the sweep | half of best << 30 | half of second << 31
+    //   w = first tile of the sweep | half of best << 28 | half of second << 30
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         typedef unsigned long long u64;
@@ -460,7 +460,251 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
             o.x = k1 == NONE ? 0xFFFFFFFFu : (uint32_t)(k1 >> 1);
             o.y = k2 == NONE ? 0xFFFFFFFFu : (uint32_t)(k2 >> 1);
             o.z = k3 == NONE ? 0xFFFFFFFFu : (uint32_t)(k3 >> 1);
-            o.w = (uint32_t)(c0 * (CHUNK / 32)) | ((uint32_t)(k1 & 1) << 30) | ((uint32_t)(k2 & 1) << 31);
+            o.w = (uint32_t)(c0 * (CHUNK / 32)) | ((uint32_t)(k1 & 1) << 28) | ((uint32_t)(k2 & 1) << 30);
+            job.partial[(size_t)wg.split * job.q_rows_alloc + q] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------- knn2_mfma (16x16) ----
+// The same sweep on v_mfma_i32_16x16x64_i8.  That shape sustains a higher clock
+// under load than 32x32x32 (measured 80 % against 67 % of the nominal peak for
+// bare MFMA loops), at the price of less idle issue time beside it.
+//
+// A wave owns 8 blocks of 16 queries (lane = query l&15, k-quarter l>>4; two
+// fragments per block for K = 128).  Train rows are taken in blocks of 64 = four
+// tiles of 16; a unit is one block against one query block: 8 MFMAs leaving 16
+// accumulators per lane (tile j, register i = row 16j + 4*(l>>4) + i of the
+// block), i.e. again 16 rows of ONE query per lane, digested exactly like a
+// 32x32 unit.  Records carry the block number and the lane quarter.
+typedef int v4acc __attribute__((ext_vector_type(4)));
+
+template <int WAVES, int ABLATE>
+__global__ void __launch_bounds__(WAVES * 64, 8 / WAVES)
+knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblocks, int splits, int map_mode)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * LDS_STAGE];
+    constexpr int QB = 8;            // query blocks of 16 per wave
+    constexpr int BLK = 64;          // train rows per block
+    constexpr int NBLK = ST / BLK;   // blocks per stage
+    constexpr int U = NBLK * QB;     // units per stage
+    constexpr int QPB = WAVES * QB * 16;
+
+    const WgCoord wg = decode_wg(blockIdx.x, (uint32_t)qblocks, (uint32_t)splits, map_mode);
+    const KnnJob job = jobs[wg.job];
+    if (wg.qblock * QPB >= job.n_query) return;
+    const int c0 = wg.split * chunks_per_split;
+    const int c1 = min(c0 + chunks_per_split, job.t_chunks);
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int c16 = lane & 15;  // query within a block of 16 / train row within a tile
+    const int kq = lane >> 4;   // which 16 bytes of each 64-byte half row / which row quartet
+    const int q_base = (wg.qblock * WAVES + wave) * (QB * 16);
+
+    v4i bq[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int8_t* qp = job.q_desc + (size_t)(q_base + qb * 16 + c16) * DIM + 16 * kq;
+        bq[qb][0] = ~*(const v4i*)(qp);
+        bq[qb][1] = ~*(const v4i*)(qp + 64);
+    }
+    uint32_t m1[QB], m2[QB], m3[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) m1[qb] = m2[qb] = m3[qb] = 0xFFFFFFFFu;
+
+    // stage image in LDS and its DMA: as in the 32x32 kernel
+    const int dma_r = lane >> 3;
+    const int dma_cs = lane & 7;
+    constexpr int PIECES = ST / 8 / WAVES;
+    static_assert(WAVES % 2 == 0, "the swizzle term of a lane must not depend on the piece");
+    const uint32_t dma_off =
+        (uint32_t)((8 * wave + dma_r) * DIM + ((dma_cs ^ (4 * (wave & 1) | (dma_r >> 1))) << 4));
+    const uint32_t cin_off = (uint32_t)(lane & (ST / 4 - 1)) * 16u;
+    auto issue_stage = [&](int bufi, int row0) {
+        unsigned char* dst = lds + bufi * LDS_STAGE;
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int8_t* base = job.t_desc + (size_t)row0 * DIM + (size_t)j * (WAVES * 1024);
+            glds16(base + dma_off, dst + (wave + j * WAVES) * 1024);
+        }
+        const unsigned char* cbase = (const unsigned char*)(job.t_cin + row0);
+        if (wave == WAVES - 1 && lane < ST / 4) glds16(cbase + cin_off, dst + LDS_DESC);
+    };
+
+    // fragment addresses: row 16*tile + c16 has swizzle term (c16 >> 1) & 7 for
+    // every tile; slot 4*half + kq
+    const int swz = (c16 >> 1) & 7;
+    int a_off[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) a_off[hh] = c16 * DIM + (((4 * hh + kq) ^ swz) << 4);
+    const int c_off = LDS_DESC + 16 * kq;  // accumulator register i of tile j is row 16j + 4kq + i
+
+    v4i fa[2][4][2];   // [set][tile][half] train fragments of the current / next block
+    v4acc fc[2][4];    // [set][tile] their cin values in accumulator layout
+    v4acc acc[2][4];   // [set][tile] accumulators of the current / previous unit
+    const int n_stage = (c1 - c0) * (CHUNK / ST);
+    const int row_base = c0 * CHUNK;
+
+    auto digest_a = [&](const v4acc* a) -> uint32_t {  // first 8 of the 16 values
+        uint32_t t = umin32((uint32_t)a[0][0], (uint32_t)a[0][1]);
+        t = umin32(umin32(t, (uint32_t)a[0][2]), (uint32_t)a[0][3]);
+        t = umin32(umin32(t, (uint32_t)a[1][0]), (uint32_t)a[1][1]);
+        t = umin32(umin32(t, (uint32_t)a[1][2]), (uint32_t)a[1][3]);
+        return t;
+    };
+    auto digest_b = [&](uint32_t t, const v4acc* a) -> uint32_t {
+        t = umin32(umin32(t, (uint32_t)a[2][0]), (uint32_t)a[2][1]);
+        t = umin32(umin32(t, (uint32_t)a[2][2]), (uint32_t)a[2][3]);
+        t = umin32(umin32(t, (uint32_t)a[3][0]), (uint32_t)a[3][1]);
+        t = umin32(umin32(t, (uint32_t)a[3][2]), (uint32_t)a[3][3]);
+        return t;
+    };
+    // reads of block `blk` of the stage at `buf` into fragment set `set`: part 0..11
+    auto read_part = [&](int set, const unsigned char* buf, int blk, int part) {
+        if (part < 8) {
+            const int j = part >> 1, hh = part & 1;
+            fa[set][j][hh] = *(const v4i*)(buf + (blk * BLK + j * 16) * DIM + a_off[hh]);
+        } else {
+            const int j = part - 8;
+            fc[set][j] = *(const v4acc*)(buf + c_off + (blk * BLK + j * 16) * 4);
+        }
+    };
+
+    if (n_stage > 0) {
+        issue_stage(0, row_base);
+        if (n_stage > 1) issue_stage(1, row_base + ST);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        SFM_SB();
+#pragma unroll
+        for (int part = 0; part < 12; ++part) read_part(0, lds, 0, part);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[1][j][i] = 0;
+
+        int cur = 0;
+        uint32_t first = 0xFFFFFFFFu;
+        for (int s = 0; s < n_stage; ++s) {
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            const int nx2 = nxt == 2 ? 0 : nxt + 1;
+            const unsigned char* buf = lds + cur * LDS_STAGE;
+            const unsigned char* nbuf = lds + nxt * LDS_STAGE;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int b = u / QB, qb = u % QB, set = b & 1, nset = set ^ 1;
+                const int pqb = (u + U - 1) % U % QB;
+                const uint32_t ptile = (uint32_t)(s * NBLK + (u == 0 ? -1 : (u - 1) / QB));
+                const v4acc* pa = acc[(u + 1) & 1];
+                v4acc* ca = acc[u & 1];
+                // next block: the next one of this stage, or block 0 of the next stage
+                const unsigned char* nb = b < NBLK - 1 ? buf : nbuf;
+                const int nblk = b < NBLK - 1 ? b + 1 : 0;
+                uint32_t tmin = 0, p = 0;
+                // first halves of the four tiles, then second halves: dependent MFMAs
+                // are four issues apart
+                ca[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][0][0], bq[qb][0], fc[set][0], 0, 0, 0);
+                SFM_SB();
+                // 12 reads per block over 8 units: 2,2,2,2,1,1,1,1
+                if (qb < 4) {
+                    read_part(nset, nb, nblk, 2 * qb);
+                    read_part(nset, nb, nblk, 2 * qb + 1);
+                } else {
+                    read_part(nset, nb, nblk, 4 + qb);
+                }
+                if (u == 1 && ABLATE < 4) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    SFM_SB();
+                }
+                if (u == 1 && ABLATE < 3) issue_stage(nx2, row_base + min(s + 2, n_stage - 1) * ST);
+                SFM_SB();
+                ca[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][1][0], bq[qb][0], fc[set][1], 0, 0, 0);
+                SFM_SB();
+                if (ABLATE < 2) tmin = digest_a(pa);
+                SFM_SB();
+                ca[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][2][0], bq[qb][0], fc[set][2], 0, 0, 0);
+                SFM_SB();
+                ca[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][3][0], bq[qb][0], fc[set][3], 0, 0, 0);
+                SFM_SB();
+                if (ABLATE < 2) tmin = digest_b(tmin, pa);
+                SFM_SB();
+                ca[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][0][1], bq[qb][1], ca[0], 0, 0, 0);
+                SFM_SB();
+                ca[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][1][1], bq[qb][1], ca[1], 0, 0, 0);
+                SFM_SB();
+                if (ABLATE < 2) {
+                    p = (tmin << TILE_BITS) | ptile;
+                    if (u == 0) p |= first;
+                }
+                SFM_SB();
+                ca[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][2][1], bq[qb][1], ca[2], 0, 0, 0);
+                SFM_SB();
+                ca[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][3][1], bq[qb][1], ca[3], 0, 0, 0);
+                SFM_SB();
+                if (ABLATE < 2) {
+                    const uint32_t n3 = umin32(m3[pqb], umax32(m2[pqb], p));
+                    const uint32_t n2 = umed3(m1[pqb], m2[pqb], p);
+                    m1[pqb] = umin32(m1[pqb], p);
+                    m2[pqb] = n2;
+                    m3[pqb] = n3;
+                } else {
+                    asm volatile("" ::"v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]));
+                }
+                SFM_SB();
+            }
+            first = 0;
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ABLATE < 2) {
+            const v4acc* pa = acc[(U - 1) & 1];
+            const uint32_t tmin = digest_b(digest_a(pa), pa);
+            const uint32_t p = (tmin << TILE_BITS) | (uint32_t)(n_stage * NBLK - 1);
+            const uint32_t n3 = umin32(m3[QB - 1], umax32(m2[QB - 1], p));
+            const uint32_t n2 = umed3(m1[QB - 1], m2[QB - 1], p);
+            m1[QB - 1] = umin32(m1[QB - 1], p);
+            m2[QB - 1] = n2;
+            m3[QB - 1] = n3;
+        } else {
+            const v4acc* pa = acc[(U - 1) & 1];
+            asm volatile("" ::"v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]));
+        }
+    }
+
+    // The four lanes l&15 + 16*quarter hold the same query over disjoint groups:
+    // merge their triples (two butterfly steps); the quarter-0 lane writes one
+    // record per (part, query):
+    //   x = best group (x << 9 | block), y = second group, z = third minimum,
+    //   w = first block of the sweep | quarter of best << 28 | quarter of second << 30
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        typedef unsigned long long u64;
+        const u64 NONE = ~0ull;
+        auto key = [&](uint32_t p) -> u64 { return p == 0xFFFFFFFFu ? NONE : (((u64)p << 2) | (u64)kq); };
+        u64 k1 = key(m1[qb]), k2 = key(m2[qb]), k3 = key(m3[qb]);
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const u64 b[3] = {(u64)__shfl_xor((unsigned long long)k1, off), (u64)__shfl_xor((unsigned long long)k2, off),
+                              (u64)__shfl_xor((unsigned long long)k3, off)};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const u64 v = b[j];
+                if (v < k3) {
+                    k3 = v;
+                    if (k3 < k2) { const u64 t = k2; k2 = k3; k3 = t; }
+                    if (k2 < k1) { const u64 t = k1; k1 = k2; k2 = t; }
+                }
+            }
+        }
+        if (kq == 0) {
+            const int q = q_base + qb * 16 + c16;
+            uint4 o;
+            o.x = k1 == NONE ? 0xFFFFFFFFu : (uint32_t)(k1 >> 2);
+            o.y = k2 == NONE ? 0xFFFFFFFFu : (uint32_t)(k2 >> 2);
+            o.z = k3 == NONE ? 0xFFFFFFFFu : (uint32_t)(k3 >> 2);
+            o.w = (uint32_t)(c0 * (CHUNK / BLK)) | ((uint32_t)(k1 & 3) << 28) | ((uint32_t)(k2 & 3) << 30);
             job.partial[(size_t)wg.split * job.q_rows_alloc + q] = o;
         }
     }
@@ -507,9 +751,18 @@ __device__ __forceinline__ void insert3(u64& a1, u64& a2, u64& a3, u64 v)
 //     not exceed the key of the second neighbour found (a tie between group
 //     minima), or if d2 >= 2^22 where different d2 share one float sqrt, the
 //     query is queued for the exhaustive float-ranked pass instead.
+// GM selects the group geometry of the sweep that wrote the records:
+//   GM = 0  32x32 tiles: unit = tile of 32 rows, sub = half h (1 bit),
+//           group rows = 32*tile + 8g + 4h + i            (g, i = 0..3)
+//   GM = 1  16x16 tiles: unit = block of 64 rows, sub = quarter (2 bits),
+//           group rows = 64*block + 16j + 4*quarter + i   (j, i = 0..3)
+template <int GM>
 __global__ void __launch_bounds__(256)
 knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblocks, int map_mode)
 {
+    constexpr int SB = GM ? 2 : 1;           // bits of the sub-unit index
+    constexpr int UROWS = GM ? 64 : 32;      // rows per unit
+    constexpr int JSTRIDE = GM ? 16 : 8;     // row stride between the four runs of a group
     // same workgroup -> XCD affinity as the sweep: the gathers of one job's
     // train rows then hit a single L2
     const WgCoord wg = decode_wg(blockIdx.x, (uint32_t)qblocks, 1u, map_mode);
@@ -520,20 +773,22 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
     const u64 NONE = ~0ull;
     const uint32_t tmask = (1u << TILE_BITS) - 1u;
     u64 c1 = NONE, c2 = NONE, c3 = NONE;
+    // key = x << 32 | (unit << SB | sub): ascending (x, unit, sub)
+    auto key_of = [&](uint32_t p, uint32_t t0, uint32_t sub) -> u64 {
+        return ((u64)(p >> TILE_BITS) << 32) | (((t0 + (p & tmask)) << SB) | sub);
+    };
     auto take = [&](const uint4 r) {
-        const uint32_t t0 = r.w & 0x3FFFFFFFu;
-        if (r.x != 0xFFFFFFFFu)
-            insert3(c1, c2, c3, ((u64)(r.x >> TILE_BITS) << 32) | (((t0 + (r.x & tmask)) << 1) | (r.w >> 30 & 1u)));
-        if (r.y != 0xFFFFFFFFu)
-            insert3(c1, c2, c3, ((u64)(r.y >> TILE_BITS) << 32) | (((t0 + (r.y & tmask)) << 1) | (r.w >> 31)));
+        const uint32_t t0 = r.w & 0x0FFFFFFFu;
+        if (r.x != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.x, t0, (r.w >> 28) & 3u));
+        if (r.y != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.y, t0, (r.w >> 30) & 3u));
         if (r.z != 0xFFFFFFFFu) insert3(c1, c2, c3, ((u64)(r.z >> TILE_BITS) << 32) | 0xFFFFFFFFu);
     };
     if (n_splits == 1) {
-        // a single record is already in ascending (x, tile, half) order
+        // a single record is already in ascending (x, unit, sub) order
         const uint4 r = job.partial[q];
-        const uint32_t t0 = r.w & 0x3FFFFFFFu;
-        if (r.x != 0xFFFFFFFFu) c1 = ((u64)(r.x >> TILE_BITS) << 32) | (((t0 + (r.x & tmask)) << 1) | (r.w >> 30 & 1u));
-        if (r.y != 0xFFFFFFFFu) c2 = ((u64)(r.y >> TILE_BITS) << 32) | (((t0 + (r.y & tmask)) << 1) | (r.w >> 31));
+        const uint32_t t0 = r.w & 0x0FFFFFFFu;
+        if (r.x != 0xFFFFFFFFu) c1 = key_of(r.x, t0, (r.w >> 28) & 3u);
+        if (r.y != 0xFFFFFFFFu) c2 = key_of(r.y, t0, (r.w >> 30) & 3u);
         if (r.z != 0xFFFFFFFFu) c3 = ((u64)(r.z >> TILE_BITS) << 32) | 0xFFFFFFFFu;
     } else {
         for (int j = l; j < n_splits; j += 32) take(job.partial[(size_t)j * job.q_rows_alloc + q]);
@@ -549,22 +804,24 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
         c3 = __shfl(c3, 0, 32);
     }
     const uint32_t third_x = (uint32_t)(c3 >> 32);  // 0xFFFFFFFF when there is no third group
-    // c1 < c2 compares (x, tile, half).  For the lane order to be the row order
-    // the group with the smaller (tile, half) must come first.
+    // c1 < c2 compares (x, unit, sub).  For the lane order to be the row order
+    // the group with the smaller (unit, sub) must come first.
     const uint32_t ida = (uint32_t)c1, idb = (uint32_t)c2;
     const bool have_a = c1 != NONE, have_b = c2 != NONE;
     const uint32_t id_lo = (!have_b || ida < idb) ? ida : idb;
     const uint32_t id_hi = (!have_b || ida < idb) ? idb : ida;
-    const bool same_tile = have_b && (id_lo >> 1) == (id_hi >> 1);
+    const bool same_unit = have_b && (id_lo >> SB) == (id_hi >> SB);
+    const int unit_lo = (int)(id_lo >> SB) * UROWS, unit_hi = (int)(id_hi >> SB) * UROWS;
+    const int sub_lo = 4 * (int)(id_lo & ((1u << SB) - 1u)), sub_hi = 4 * (int)(id_hi & ((1u << SB) - 1u));
     // candidate position 0..31 -> train row (ascending), -1 when there is none;
-    // written without branches (selects only)
-    const int tile_lo = (int)(id_lo >> 1) * 32, tile_hi = (int)(id_hi >> 1) * 32;
-    const int half_lo = 4 * (int)(id_lo & 1), half_hi = 4 * (int)(id_hi & 1);
+    // written without branches (selects only).  Two groups of one unit interleave:
+    // position = 8*run + 4*which + i.
     auto row_of = [&](int pos) -> int {
         const int i = pos & 15;
         const bool hi = pos >= 16;
-        const int split_row = (hi ? tile_hi + half_hi : tile_lo + half_lo) + 8 * (i >> 2) + (i & 3);
-        const int r = same_tile ? tile_lo + pos : split_row;
+        const int split_row = (hi ? unit_hi + sub_hi : unit_lo + sub_lo) + JSTRIDE * (i >> 2) + (i & 3);
+        const int same_row = unit_lo + JSTRIDE * (pos >> 3) + ((pos >> 2) & 1 ? sub_hi : sub_lo) + (pos & 3);
+        const int r = same_unit ? same_row : split_row;
         const bool none = !have_a || (hi && !have_b);
         return none ? -1 : r;
     };
@@ -580,15 +837,16 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
     const int qn = job.q_qn[q];
     const int tn = job.t_qn[row_ok ? row : 0];
     const v4i qv = *(const v4i*)(job.q_desc + (size_t)q * DIM + sg * 16);
-    // rows of candidates 4*it + rq: position 4*it + rq is in the low group for
-    // it < 4 (i = 4*it + rq, so i>>2 = it, i&3 = rq) and in the high one after
-    const int base_lo = have_a ? tile_lo + half_lo + rq : 0;
-    const int base_hi = have_b ? tile_hi + half_hi + rq : 0;
-    const int base_same = tile_lo + rq;
+    // rows of candidates 4*it + rq (i = rq): in two different units the position
+    // is in the low group for it < 4 (run = it) and in the high one after; in
+    // one unit run = it >> 1 and the group alternates with it
+    const int base_lo = have_a ? unit_lo + sub_lo + rq : 0;
+    const int base_hi = have_b ? unit_hi + sub_hi + rq : 0;
     v4i tv[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-        const int r = same_tile ? base_same + 4 * it : (it < 4 ? base_lo : base_hi) + 8 * (it & 3);
+        const int r = same_unit ? ((it & 1) ? base_hi : base_lo) + JSTRIDE * (it >> 1)
+                                : (it < 4 ? base_lo : base_hi) + JSTRIDE * (it & 3);
         tv[it] = *(const v4i*)(job.t_desc + (size_t)r * DIM + sg * 16);
     }
     int part[8];
@@ -808,6 +1066,20 @@ __global__ void __launch_bounds__(64) mfma_layout_probe_kernel(const int8_t* A, 
     }
 }
 
+// C(16x16) = A(16 rows x 64 k) * B^T (B given as [16 cols][64 k]) through one
+// v_mfma_i32_16x16x64_i8 with the operand and accumulator mapping the 16x16
+// sweep assumes.
+__global__ void __launch_bounds__(64) mfma16_layout_probe_kernel(const int8_t* A, const int8_t* B, int32_t* C)
+{
+    const int lane = threadIdx.x, c16 = lane & 15, kq = lane >> 4;
+    const v4i a = *(const v4i*)(A + c16 * 64 + 16 * kq);
+    const v4i b = *(const v4i*)(B + c16 * 64 + 16 * kq);
+    v4acc c = {0, 0, 0, 0};
+    c = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) C[(4 * kq + i) * 16 + c16] = c[i];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- hosts ----
@@ -826,14 +1098,16 @@ hipError_t launch_prep_rows(hipStream_t s, const PrepJob* jobs_dev, int n_jobs, 
 // Workgroup shapes of the distance kernel: {query blocks per wave, waves}.
 //   0: 4 x 4 (512 queries / workgroup)   1: 2 x 4 (256)
 //   2: 2 x 8 (512)                       3: 4 x 8 (1024)
-static const int kVariantQPB[4] = {512, 256, 512, 1024};
+//   4: 16x16x64 MFMAs, 8 x 4 waves (512 queries / workgroup), groups over 64-row blocks
+static const int kVariantQPB[5] = {512, 256, 512, 1024, 512};
 
 KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant)
 {
     KnnPlan p;
     p.ablate = force_variant >= 0 ? force_variant / 16 : 0;
     if (force_variant >= 0) force_variant %= 16;
-    p.variant = (force_variant >= 0 && force_variant < 4) ? force_variant : 0;
+    p.variant = (force_variant >= 0 && force_variant < 5) ? force_variant : 4;  // 16x16x64 unless forced
+    p.group_mode = p.variant == 4 ? 1 : 0;
     p.q_per_block = kVariantQPB[p.variant];
     const int t_chunks = (n_train_max + CHUNK - 1) / CHUNK;
     const long long qblocks = (long long)((n_query_max + p.q_per_block - 1) / p.q_per_block) * n_jobs;
@@ -843,7 +1117,7 @@ KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant
     int splits = (t_chunks + MAX_SWEEP_CHUNKS - 1) / MAX_SWEEP_CHUNKS;
     if (splits < 1) splits = 1;
     // two resident workgroups per CU for the 4-wave shapes, one for the 8-wave ones
-    const long long want = (p.variant == 0 || p.variant == 1) ? 512 : 256;
+    const long long want = (p.variant == 0 || p.variant == 1 || p.variant == 4) ? 512 : 256;
     while (qblocks * splits < want && splits * 2 <= t_chunks && t_chunks / (splits * 2) >= 2)
         splits *= 2;
     p.n_splits = splits;
@@ -870,6 +1144,15 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
         case 1: SFM_KNN2(2, 4, 0); break;
         case 2: SFM_KNN2(2, 8, 0); break;
         case 3: SFM_KNN2(4, 8, 0); break;
+        case 4:
+#define SFM_KNN16(ABL)                                                                            \
+    hipLaunchKernelGGL((knn2_mfma16_kernel<4, ABL>), grid, dim3(256), 0, s, jobs_dev, plan.chunks_per_split, \
+                       qblocks, splits, mode)
+            if (plan.ablate == 2) SFM_KNN16(2);
+            else if (plan.ablate == 4) SFM_KNN16(4);
+            else SFM_KNN16(0);
+#undef SFM_KNN16
+            break;
         default:
             if (plan.ablate == 2) SFM_KNN2(4, 4, 2);
             else if (plan.ablate == 3) SFM_KNN2(4, 4, 3);
@@ -882,14 +1165,19 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
 }
 
 hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_query_max,
-                               int n_splits, int k)
+                               int n_splits, int k, int group_mode)
 {
     const int qblocks = (n_query_max + 7) / 8;
     if (qblocks <= 0 || n_jobs <= 0) return hipSuccess;
     const long long total = (long long)qblocks * n_jobs;
     if (total > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(knn_rescan_kernel, dim3((unsigned)total), dim3(256), 0, s, jobs_dev, n_splits, k, qblocks,
-                       n_jobs % 8 == 0 ? 1 : 0);
+    const int mode = n_jobs % 8 == 0 ? 1 : 0;
+    if (group_mode)
+        hipLaunchKernelGGL(knn_rescan_kernel<1>, dim3((unsigned)total), dim3(256), 0, s, jobs_dev, n_splits, k,
+                           qblocks, mode);
+    else
+        hipLaunchKernelGGL(knn_rescan_kernel<0>, dim3((unsigned)total), dim3(256), 0, s, jobs_dev, n_splits, k,
+                           qblocks, mode);
     return hipGetLastError();
 }
 
@@ -908,6 +1196,11 @@ hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, in
 hipError_t launch_mfma_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c)
 {
     hipLaunchKernelGGL(mfma_layout_probe_kernel, dim3(1), dim3(64), 0, s, a, b, c);
+    return hipGetLastError();
+}
+hipError_t launch_mfma16_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c)
+{
+    hipLaunchKernelGGL(mfma16_layout_probe_kernel, dim3(1), dim3(64), 0, s, a, b, c);
     return hipGetLastError();
 }
 

@@ -510,7 +510,7 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
         }
         {
             ProfScope ps(ctx, "knn_finalize");
-            SFM_HIP(ctx, launch_knn_finalize(s, djobs, g, nq_max, plan.n_splits, 2));
+            SFM_HIP(ctx, launch_knn_finalize(s, djobs, g, nq_max, plan.n_splits, 2, plan.group_mode));
         }
         {
             ProfScope ps(ctx, "knn_redo");

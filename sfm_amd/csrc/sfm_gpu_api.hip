@@ -109,7 +109,7 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
     }
     {
         ProfScope ps(ctx, "knn_finalize");
-        SFM_HIP(ctx, launch_knn_finalize(ctx->stream, ctx->jobs.as<KnnJob>(), 1, nq, plan.n_splits, k));
+        SFM_HIP(ctx, launch_knn_finalize(ctx->stream, ctx->jobs.as<KnnJob>(), 1, nq, plan.n_splits, k, plan.group_mode));
     }
     {
         ProfScope ps(ctx, "knn_redo");
@@ -467,6 +467,23 @@ int sfm_gpu_debug_mfma_probe(sfm_gpu_ctx* ctx, const int8_t* a, const int8_t* b,
     SFM_HIP(ctx, hipMemcpyAsync(db, b, 1024, hipMemcpyHostToDevice, ctx->stream));
     SFM_HIP(ctx, launch_mfma_layout_probe(ctx->stream, da, db, dc));
     SFM_HIP(ctx, hipMemcpyAsync(c, dc, 4096, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFM_GPU_OK;
+}
+
+// c[16][16] = a[16][64] * b^T, b given as [16 columns][64 k]; host pointers.
+int sfm_gpu_debug_mfma16_probe(sfm_gpu_ctx* ctx, const int8_t* a, const int8_t* b, int32_t* c)
+{
+    if (!ctx || !a || !b || !c) return SFM_GPU_ERR_ARG;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, ctx->rs_misc.reserve(1024 + 1024 + 1024));
+    int8_t* da = ctx->rs_misc.as<int8_t>();
+    int8_t* db = da + 1024;
+    int32_t* dc = (int32_t*)(da + 2048);
+    SFM_HIP(ctx, hipMemcpyAsync(da, a, 1024, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP(ctx, hipMemcpyAsync(db, b, 1024, hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP(ctx, launch_mfma16_layout_probe(ctx->stream, da, db, dc));
+    SFM_HIP(ctx, hipMemcpyAsync(c, dc, 1024, hipMemcpyDeviceToHost, ctx->stream));
     SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SFM_GPU_OK;
 }

@@ -94,14 +94,16 @@ struct KnnPlan {
     int chunks_per_split;
     int q_per_block;
     int variant;
-    int ablate;  // timing experiments only: 1 = never update, 2 = MFMA only (wrong results)
+    int ablate;  // timing experiments only: 2 = MFMA only, 3 = no DMA, 4 = no barrier either (wrong results)
+    int group_mode;  // geometry of the row groups in the sweep's records: 0 = 32x32 tiles, 1 = 16x16 tiles
 };
 KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant);
 hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_rows_alloc_max,
                        const KnnPlan& plan);
 hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_query_max,
-                               int n_splits, int k);
+                               int n_splits, int k, int group_mode);
 hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_splits, int k);
 hipError_t launch_mfma_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c);
+hipError_t launch_mfma16_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c);
 
 }  // namespace sfm

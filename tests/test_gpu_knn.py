@@ -33,7 +33,17 @@ def test_mfma_operand_and_accumulator_layout(gpu_ctx):
     assert (c == ref).all()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_mfma16_operand_and_accumulator_layout(gpu_ctx):
+    rng = np.random.default_rng(1)
+    a = rng.integers(-128, 128, (16, 64)).astype(np.int8)
+    b = rng.integers(-128, 128, (16, 64)).astype(np.int8)   # [col][k]
+    c = np.zeros((16, 16), np.int32)
+    gpu_ctx.check(gpu_ctx._L.sfm_gpu_debug_mfma16_probe(gpu_ctx.handle, matcher.ptr(a), matcher.ptr(b),
+                                                         matcher.ptr(c)))
+    assert (c == a.astype(np.int32) @ b.astype(np.int32).T).all()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("nq,nt", [(1, 1), (5, 2), (33, 257), (257, 1000), (700, 3000)])
 def test_knn_small_shapes(gpu_ctx, oracle, variant, nq, nt):
     gpu_ctx._L.sfm_gpu_debug_set_knn_variant(gpu_ctx.handle, variant)
@@ -45,7 +55,15 @@ def test_knn_small_shapes(gpu_ctx, oracle, variant, nq, nt):
     gpu_ctx._L.sfm_gpu_debug_set_knn_variant(gpu_ctx.handle, -1)
 
 
-def test_knn_sift_like_planted(gpu_ctx, oracle):
+@pytest.fixture(params=[-1, 0], ids=["planner_mfma16x16", "mfma32x32"])
+def sweep_shape(request, gpu_ctx):
+    """Runs a test with the planner's choice and with each MFMA shape of the sweep forced."""
+    gpu_ctx._L.sfm_gpu_debug_set_knn_variant(gpu_ctx.handle, request.param)
+    yield request.param
+    gpu_ctx._L.sfm_gpu_debug_set_knn_variant(gpu_ctx.handle, -1)
+
+
+def test_knn_sift_like_planted(gpu_ctx, oracle, sweep_shape):
     Q, T, planted = synth.planted_pair(4096, 4096, 1001, 1002, 1003)
     gm, gc = matcher.BFMatcher(gpu_ctx).knnMatch(Q, T, 2)
     om, oc = oracle.knn_match(Q, T, 2, nthreads=8)
@@ -55,7 +73,7 @@ def test_knn_sift_like_planted(gpu_ctx, oracle):
     assert (gm["trainIdx"][keep, 0] == planted[keep]).mean() > 0.99
 
 
-def test_knn_ties_across_tiles_chunks_and_splits(gpu_ctx, oracle):
+def test_knn_ties_across_tiles_chunks_and_splits(gpu_ctx, oracle, sweep_shape):
     # duplicated train rows far apart: ties must resolve to the lowest row
     rng = np.random.default_rng(9)
     t = rng.integers(0, 256, (5000, 128)).astype(np.float32)
@@ -78,7 +96,7 @@ def test_knn_ties_across_tiles_chunks_and_splits(gpu_ctx, oracle):
     assert gm["trainIdx"][40].tolist() == [700, 2900]
 
 
-def test_knn_extremes_and_float_collision(gpu_ctx, oracle):
+def test_knn_extremes_and_float_collision(gpu_ctx, oracle, sweep_shape):
     # all-0 / all-255 rows (d2 = 8323200) and engineered d2 >= 2^22 collisions
     q = np.zeros((4, 128), np.float32)
     q[1] = 255
@@ -140,7 +158,7 @@ def test_knn_rejects_non_integer_values(gpu_ctx):
     assert e.value.code == -5
 
 
-def test_knn_full_size_8k_against_oracle(gpu_ctx, oracle):
+def test_knn_full_size_8k_against_oracle(gpu_ctx, oracle, sweep_shape):
     Q, T, _ = synth.planted_pair(8192, 8192, 1001, 1002, 1003)
     gm, gc = matcher.BFMatcher(gpu_ctx).knnMatch(Q, T, 2)
     om, oc = oracle.knn_match(Q, T, 2, nthreads=16)
@@ -181,7 +199,7 @@ def _numpy_top2(Q, T, rows):
 
 
 @pytest.mark.parametrize("nq,nt,seed", [(20000, 20000, 1201), (32768, 32768, 1202), (9001, 30011, 1203)])
-def test_knn_large_ragged_sizes_against_numpy_sample(gpu_ctx, nq, nt, seed):
+def test_knn_large_ragged_sizes_against_numpy_sample(gpu_ctx, nq, nt, seed, sweep_shape):
     # sizes of the larger configurations (20k x 20k views, 32k x 32k pair, a ragged
     # pair): a random sample of query rows is checked against an independent exact
     # computation, which does not depend on the size the CPU oracle can finish
