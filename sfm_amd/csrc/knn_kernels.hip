@@ -622,33 +622,55 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
                 SFM_SB();
                 ca[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][1][0], bq[qb][0], fc[set][1], 0, 0, 0);
                 SFM_SB();
-                if (ABLATE < 2) tmin = digest_a(pa);
+                // the digest of the previous unit, two instructions per MFMA gap
+                if (ABLATE < 2) {
+                    tmin = umin32((uint32_t)pa[0][0], (uint32_t)pa[0][1]);
+                    tmin = umin32(umin32(tmin, (uint32_t)pa[0][2]), (uint32_t)pa[0][3]);
+                }
                 SFM_SB();
                 ca[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][2][0], bq[qb][0], fc[set][2], 0, 0, 0);
                 SFM_SB();
+                if (ABLATE < 2) {
+                    tmin = umin32(umin32(tmin, (uint32_t)pa[1][0]), (uint32_t)pa[1][1]);
+                    tmin = umin32(umin32(tmin, (uint32_t)pa[1][2]), (uint32_t)pa[1][3]);
+                }
+                SFM_SB();
                 ca[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][3][0], bq[qb][0], fc[set][3], 0, 0, 0);
                 SFM_SB();
-                if (ABLATE < 2) tmin = digest_b(tmin, pa);
+                if (ABLATE < 2) {
+                    tmin = umin32(umin32(tmin, (uint32_t)pa[2][0]), (uint32_t)pa[2][1]);
+                    tmin = umin32(umin32(tmin, (uint32_t)pa[2][2]), (uint32_t)pa[2][3]);
+                }
                 SFM_SB();
                 ca[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][0][1], bq[qb][1], ca[0], 0, 0, 0);
                 SFM_SB();
+                if (ABLATE < 2) {
+                    tmin = umin32(umin32(tmin, (uint32_t)pa[3][0]), (uint32_t)pa[3][1]);
+                    tmin = umin32(umin32(tmin, (uint32_t)pa[3][2]), (uint32_t)pa[3][3]);
+                }
+                SFM_SB();
                 ca[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][1][1], bq[qb][1], ca[1], 0, 0, 0);
                 SFM_SB();
+                uint32_t mx = 0;
                 if (ABLATE < 2) {
                     p = (tmin << TILE_BITS) | ptile;
                     if (u == 0) p |= first;
+                    mx = umax32(m2[pqb], p);
                 }
                 SFM_SB();
                 ca[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][2][1], bq[qb][1], ca[2], 0, 0, 0);
                 SFM_SB();
+                uint32_t n2 = 0;
+                if (ABLATE < 2) {
+                    m3[pqb] = umin32(m3[pqb], mx);
+                    n2 = umed3(m1[pqb], m2[pqb], p);
+                }
+                SFM_SB();
                 ca[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][3][1], bq[qb][1], ca[3], 0, 0, 0);
                 SFM_SB();
                 if (ABLATE < 2) {
-                    const uint32_t n3 = umin32(m3[pqb], umax32(m2[pqb], p));
-                    const uint32_t n2 = umed3(m1[pqb], m2[pqb], p);
                     m1[pqb] = umin32(m1[pqb], p);
                     m2[pqb] = n2;
-                    m3[pqb] = n3;
                 } else {
                     asm volatile("" ::"v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]));
                 }
