@@ -51,7 +51,7 @@ size_t ransac_ws_bytes(int cap, int hyp_cap, int m)
     size_t b = 0;
     b += align_up((size_t)cap * 16, 256) * 2;            // x1, x2
     b += align_up((size_t)cap * 8, 256) * 2;             // f1, f2
-    b += align_up((size_t)(cap + 2) * 16, 256);          // soa
+    b += align_up(((size_t)cap + 7) / 4 * 64, 256);      // soa: blocks of four points
     b += align_up((size_t)hyp_cap * m * 4, 256);         // table
     b += align_up((size_t)hyp_cap * 90 * 8, 256);        // models
     b += align_up((size_t)hyp_cap * 4, 256);             // nmodels
@@ -71,7 +71,7 @@ void carve_ransac(RansacProb& pb, char* base, int cap, int hyp_cap, int m)
     pb.f1 = (float*)take((size_t)cap * 8);
     pb.f2 = (float*)take((size_t)cap * 8);
     pb.cap_pad = (cap + 2) & ~1;
-    pb.soa = (float*)take((size_t)(cap + 2) * 16);
+    pb.soa = (float*)take(((size_t)cap + 7) / 4 * 64);
     pb.table = (int32_t*)take((size_t)hyp_cap * m * 4);
     pb.models = (double*)take((size_t)hyp_cap * 90 * 8);
     pb.nmodels = (int32_t*)take((size_t)hyp_cap * 4);

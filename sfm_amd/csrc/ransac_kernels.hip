@@ -935,10 +935,13 @@ __global__ void __launch_bounds__(256) ransac_prep_kernel(const RansacProb* __re
     // float32 planes X1, Y1, X2, Y2 of the coordinates the error function works
     // on (exact for the fundamental model, rounded for the essential one): the
     // scoring kernel's single-precision filter reads pairs of points from them
-    pb.soa[0 * (size_t)pb.cap_pad + i] = (float)pb.x1[2 * i];
-    pb.soa[1 * (size_t)pb.cap_pad + i] = (float)pb.x1[2 * i + 1];
-    pb.soa[2 * (size_t)pb.cap_pad + i] = (float)pb.x2[2 * i];
-    pb.soa[3 * (size_t)pb.cap_pad + i] = (float)pb.x2[2 * i + 1];
+    // layout: blocks of four points, [block][X1 Y1 X2 Y2][4]: one 64-byte scalar
+    // load brings four points with pairs of equal coordinates adjacent
+    float* blk = pb.soa + (size_t)(i >> 2) * 16 + (i & 3);
+    blk[0] = (float)pb.x1[2 * i];
+    blk[4] = (float)pb.x1[2 * i + 1];
+    blk[8] = (float)pb.x2[2 * i];
+    blk[12] = (float)pb.x2[2 * i + 1];
 }
 
 struct CvRng {
@@ -1260,7 +1263,7 @@ __global__ void __launch_bounds__(1024) ransac_compact_kernel(const RansacProb* 
         for (int i = tid; i < n; i += 1024)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                mx = max(mx, __float_as_int(fabsf(pb.soa[(size_t)c * pb.cap_pad + i])));
+                mx = max(mx, __float_as_int(fabsf(pb.soa[(size_t)(i >> 2) * 16 + c * 4 + (i & 3)])));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
         if (lane == 0) wsum[wv] = mx;
@@ -1534,7 +1537,6 @@ __global__ void __launch_bounds__(64) ransac_score_kernel(const RansacProb* __re
         float Mf[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) Mf[k] = (float)M[k];
-        const size_t cp = (size_t)pb.cap_pad;
         typedef const float __attribute__((address_space(4))) cfloat;
         cfloat* S = (cfloat*)(uintptr_t)pb.soa;
         auto park = [&](int idx) {
@@ -1546,15 +1548,14 @@ __global__ void __launch_bounds__(64) ransac_score_kernel(const RansacProb* __re
                 cnt += exact(idx);
             }
         };
-        // four points per step, the next four already on their way
+        // four points per step (one 64-byte block: X1[4] Y1[4] X2[4] Y2[4]), the
+        // next four already on their way; i0 is a multiple of 4
         const int i4 = i0 + ((i1 - i0) & ~3);
         f2v nx[8];
         auto fetch = [&](int at) {
+            cf2v* B = (cf2v*)(S + (size_t)(at >> 2) * 16);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                nx[2 * c] = *(cf2v*)(S + c * cp + at);
-                nx[2 * c + 1] = *(cf2v*)(S + c * cp + at + 2);
-            }
+            for (int k = 0; k < 8; ++k) nx[k] = B[k];
         };
         if (i < i4) fetch(i);
         for (; i < i4; i += 4) {
