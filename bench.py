@@ -3,8 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): image pairs of 8192 x 8192 synthetic SIFT
-descriptors; per pair  kNN(k=2) -> ratio test (0.7) -> fundamental-matrix
+Workload: image pairs of 8192 x 8192 synthetic SIFT descriptors; per pair
+kNN(k=2) -> ratio test (0.7) -> fundamental-matrix
 RANSAC with 2048 hypotheses (fixed count) -> inlier selection.  One step
 processes a batch of independent pairs (--pairs-per-step, default 64) whose
 float32 descriptors and keypoints are already resident in HBM; the conversion

@@ -142,16 +142,6 @@ constexpr int LDS_DESC = ST * DIM;           // descriptors of one stage
 constexpr int LDS_STAGE = LDS_DESC + ST * 4; // + cin[ST]
 constexpr int TILE_BITS = 9;                 // a sweep holds at most 512 tiles of 32 rows
 
-// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f)
-{
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
-
 // 16 bytes per lane from global memory straight into LDS at
 // lds_wave_base + 16 * lane (the LDS side of the instruction is not a scatter).
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base)

@@ -28,7 +28,6 @@ constexpr int ROW_ALIGN = 1024;
 // 0..255-valued rows: 23 bits, so (x << 9) | tile fits 32 bits.
 constexpr int KEY_OFFSET = 2080896;
 constexpr int PAD_CIN = 0x7FFFFF;  // padding rows rank behind every real row
-constexpr uint32_t KEY_NONE = 0xFFFFFFu;
 
 // One image's descriptors as the distance kernel wants them.
 //   desc[r][d]  = value - 128 as int8 (byte = value ^ 0x80)
