@@ -200,6 +200,50 @@ double solve_bracket(const double* P, const double* dP, int n, double lo, double
     return x;
 }
 
+// The first and the last interval of a level reach out to the root bound -B / B,
+// which is usually far beyond the root they hold, and a Newton/bisection
+// iteration started from the middle of such an interval spends dozens of steps
+// coming back.  P is monotone there (no critical point beyond the outermost
+// one), so the root is bracketed first by stepping away from the finite end in
+// doubling steps (first step: 1/16 of max(1, |end|)).  Only done when P changes
+// sign over the interval.
+void tighten_open_interval(const double* P, int k, bool open_lo, bool open_hi, double& lo, double& hi,
+                           double& flo, double& fhi)
+{
+    if (flo == 0.0 || fhi == 0.0 || ((flo < 0.0) == (fhi < 0.0))) return;
+    if (open_hi) {
+        double w = 0.0625 * std::max(1.0, std::fabs(lo));
+        const double e = lo;
+        double a = lo, fa = flo;
+        for (;;) {
+            const double x = e + w;
+            if (!(x < hi)) break;
+            const double fx = horner(P, k, x);
+            if (fx == 0.0 || ((fx < 0.0) != (flo < 0.0))) { hi = x; fhi = fx; break; }
+            a = x;
+            fa = fx;
+            w = w * 2.0;
+        }
+        lo = a;
+        flo = fa;
+    } else if (open_lo) {
+        double w = 0.0625 * std::max(1.0, std::fabs(hi));
+        const double e = hi;
+        double b = hi, fb = fhi;
+        for (;;) {
+            const double x = e - w;
+            if (!(x > lo)) break;
+            const double fx = horner(P, k, x);
+            if (fx == 0.0 || ((fx < 0.0) != (fhi < 0.0))) { lo = x; flo = fx; break; }
+            b = x;
+            fb = fx;
+            w = w * 2.0;
+        }
+        hi = b;
+        fhi = fb;
+    }
+}
+
 // All real roots of c[0] + c[1] z + ... + c[n] z^n (n <= 10), ascending.
 // Level k of the recursion isolates the roots of the (n-k)-th derivative
 // between consecutive roots of the next derivative, where it is monotone.
@@ -239,6 +283,7 @@ int real_roots(const double* cin, int n, double* roots)
             if (!(hi > lo)) continue;
             double flo = horner(D[k], k, lo);
             double fhi = horner(D[k], k, hi);
+            tighten_open_interval(D[k], k, t == 0 && mprev >= 1, t == mprev && mprev >= 1, lo, hi, flo, fhi);
             if (flo == 0.0) {
                 if (mcur < 10) cur[mcur++] = lo;
             } else if (fhi != 0.0 && ((flo < 0.0) != (fhi < 0.0))) {

@@ -75,6 +75,47 @@ __device__ __forceinline__ double horner(const double* c, int n, double x)
     return s;
 }
 
+// Brackets the root of a first / last interval of a level (which reaches out to
+// the root bound) by doubling steps away from its finite end, where P is
+// monotone; see the CPU statement of the same search in oracle/.
+template <class HornerF>
+__device__ __forceinline__ void tighten_open_interval(HornerF&& P, bool open_lo, bool open_hi, double& lo,
+                                                      double& hi, double& flo, double& fhi)
+{
+    if (flo == 0.0 || fhi == 0.0 || ((flo < 0.0) == (fhi < 0.0))) return;
+    if (open_hi) {
+        double w = 0.0625 * fmax(1.0, fabs(lo));
+        const double e = lo;
+        double a = lo, fa = flo;
+        for (;;) {
+            const double x = e + w;
+            if (!(x < hi)) break;
+            const double fx = P(x);
+            if (fx == 0.0 || ((fx < 0.0) != (flo < 0.0))) { hi = x; fhi = fx; break; }
+            a = x;
+            fa = fx;
+            w = w * 2.0;
+        }
+        lo = a;
+        flo = fa;
+    } else if (open_lo) {
+        double w = 0.0625 * fmax(1.0, fabs(hi));
+        const double e = hi;
+        double b = hi, fb = fhi;
+        for (;;) {
+            const double x = e - w;
+            if (!(x > lo)) break;
+            const double fx = P(x);
+            if (fx == 0.0 || ((fx < 0.0) != (fhi < 0.0))) { lo = x; flo = fx; break; }
+            b = x;
+            fb = fx;
+            w = w * 2.0;
+        }
+        hi = b;
+        fhi = fb;
+    }
+}
+
 // Newton with bisection safeguard to a fixed point; see the CPU statement of
 // the same iteration in oracle/ for the reasoning.
 __device__ double solve_bracket(const double* P, const double* dP, int n, double lo, double hi, bool lo_neg)
@@ -232,8 +273,10 @@ __device__ int real_roots(SolveWs& w, int n, int lane)
             if (hi < -B) hi = -B;
             if (hi > B) hi = B;
             if (hi > lo) {
-                const double flo = horner(w.D[k], k, lo);
-                const double fhi = horner(w.D[k], k, hi);
+                double flo = horner(w.D[k], k, lo);
+                double fhi = horner(w.D[k], k, hi);
+                tighten_open_interval([&](double x) { return horner(w.D[k], k, x); }, t == 0 && mprev >= 1,
+                                      t == mprev && mprev >= 1, lo, hi, flo, fhi);
                 if (flo == 0.0) {
                     has = 1;
                     r = lo;
@@ -619,13 +662,14 @@ __device__ __forceinline__ double clamp_b(double v, double B)
 // derivative; appends at most one root to cur[0..2].
 template <int K>
 __device__ __forceinline__ void root_interval(const double* P, const double* dP, double lo, double hi, double B,
-                                              bool last, double* cur, int& mcur)
+                                              bool last, bool open_lo, bool open_hi, double* cur, int& mcur)
 {
     lo = clamp_b(lo, B);
     hi = clamp_b(hi, B);
     if (!(hi > lo)) return;
-    const double flo = horner_t<K>(P, lo);
-    const double fhi = horner_t<K>(P, hi);
+    double flo = horner_t<K>(P, lo);
+    double fhi = horner_t<K>(P, hi);
+    tighten_open_interval([&](double x) { return horner_t<K>(P, x); }, open_lo, open_hi, lo, hi, flo, fhi);
     bool has = false;
     double r = 0.0;
     if (flo == 0.0) {
@@ -670,15 +714,16 @@ __device__ __forceinline__ int real_roots3_thread(const double* cin, double* roo
         double cur[3] = {0.0, 0.0, 0.0};
         int mprev = 1, mcur = 0;
         // level 2: roots of the first derivative
-        root_interval<2>(D2, D1, -B, prev[0], B, false, cur, mcur);
-        root_interval<2>(D2, D1, prev[0], B, B, true, cur, mcur);
+        root_interval<2>(D2, D1, -B, prev[0], B, false, true, false, cur, mcur);
+        root_interval<2>(D2, D1, prev[0], B, B, true, false, true, cur, mcur);
         prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
         mprev = mcur;
         mcur = 0;
         // level 3: the polynomial itself, intervals t = 0..mprev
-        root_interval<3>(c, D2, -B, mprev > 0 ? prev[0] : B, B, mprev == 0, cur, mcur);
-        if (mprev >= 1) root_interval<3>(c, D2, prev[0], mprev > 1 ? prev[1] : B, B, mprev == 1, cur, mcur);
-        if (mprev >= 2) root_interval<3>(c, D2, prev[1], B, B, true, cur, mcur);
+        root_interval<3>(c, D2, -B, mprev > 0 ? prev[0] : B, B, mprev == 0, mprev >= 1, false, cur, mcur);
+        if (mprev >= 1)
+            root_interval<3>(c, D2, prev[0], mprev > 1 ? prev[1] : B, B, mprev == 1, false, mprev == 1, cur, mcur);
+        if (mprev >= 2) root_interval<3>(c, D2, prev[1], B, B, true, false, true, cur, mcur);
         roots[0] = cur[0]; roots[1] = cur[1]; roots[2] = cur[2];
         return mcur;
     }
@@ -692,8 +737,8 @@ __device__ __forceinline__ int real_roots3_thread(const double* cin, double* roo
         const double e = -D1[0] / D1[1];
         double cur[3] = {0.0, 0.0, 0.0};
         int mcur = 0;
-        root_interval<2>(c, D1, -B, e, B, false, cur, mcur);
-        root_interval<2>(c, D1, e, B, B, true, cur, mcur);
+        root_interval<2>(c, D1, -B, e, B, false, true, false, cur, mcur);
+        root_interval<2>(c, D1, e, B, B, true, false, true, cur, mcur);
         roots[0] = cur[0]; roots[1] = cur[1];
         return mcur;
     }
