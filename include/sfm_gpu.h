@@ -205,8 +205,8 @@ typedef struct sfm_gpu_match_params {
  * The body of the reference's pair loop (main.cpp:175-231, 267) for a list of
  * image pairs: kNN(k=2) -> ratio test -> RANSAC mask -> inlier matches.
  *
- *   images        array of prepared images
- *   pairs         host, n_pairs x 2 int32 (query image, train image)
+ *   images        array of n_images prepared images
+ *   pairs         host, n_pairs x 2 int32 (query image, train image), each in [0, n_images)
  *   n_good        out, per pair: ratio-test survivors  ("goodMatches.size()")
  *   n_inliers     out, per pair: RANSAC inliers        ("selectMatches.size()")
  *   inlier_matches  out, optional: n_pairs * match_capacity records; pair p's
@@ -217,7 +217,7 @@ typedef struct sfm_gpu_match_params {
  * mode FIXED on synthetic geometry supplied separately; normally keypoints are
  * required.
  */
-int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const int32_t* pairs,
+int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images, const int32_t* pairs,
                         int n_pairs, const sfm_gpu_match_params* params, int32_t* n_good,
                         int32_t* n_inliers, sfm_gpu_dmatch* inlier_matches,
                         int match_capacity);

@@ -385,14 +385,18 @@ int sfm_gpu_debug_ransac_dump(sfm_gpu_ctx* ctx, int n_hyp, int32_t* table, int32
     return SFM_GPU_OK;
 }
 
-int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const int32_t* pairs,
+int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images, const int32_t* pairs,
                         int n_pairs, const sfm_gpu_match_params* params, int32_t* n_good,
                         int32_t* n_inliers, sfm_gpu_dmatch* inlier_matches, int match_capacity)
 {
     if (!ctx) return SFM_GPU_ERR_ARG;
-    if (n_pairs < 0 || !params || (n_pairs > 0 && (!images || !pairs || !n_good || !n_inliers)))
-        return ctx->fail(SFM_GPU_ERR_ARG, "null pointer or negative pair count");
+    if (n_pairs < 0 || n_images < 0 || !params ||
+        (n_pairs > 0 && (!images || !pairs || !n_good || !n_inliers)))
+        return ctx->fail(SFM_GPU_ERR_ARG, "null pointer or negative count");
     if (n_pairs == 0) return SFM_GPU_OK;
+    for (int p = 0; p < 2 * n_pairs; ++p)
+        if (pairs[p] < 0 || pairs[p] >= n_images)
+            return ctx->fail(SFM_GPU_ERR_ARG, "pair %d names image %d of %d", p / 2, pairs[p], n_images);
     RansacParams rp;
     rp.model = params->model;
     rp.mode = params->mode;
@@ -429,15 +433,12 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
     int group = (int)std::min<size_t>((size_t)n_pairs,
                                       std::max<size_t>(1, ((size_t)3 << 30) / (per_pair_ransac + 1)));
     group = std::min(group, 256);
-    const KnnPlan plan_probe = plan_knn(nq_max, nt_max, group, ctx->knn_variant);
-    const size_t partial_b = align_up((size_t)plan_probe.n_splits * qalloc_max * sizeof(uint4), 256);
     const size_t out_b = align_up((size_t)nq_max * 2 * sizeof(sfm_gpu_dmatch), 256);
     const size_t cnt_b = align_up((size_t)nq_max * 4, 256);
     const size_t redo_b = align_up(((size_t)nq_max + 1) * 4, 256);
     const size_t good_b = align_up((size_t)nq_max * sizeof(sfm_gpu_dmatch), 256);
     const size_t px_b = align_up((size_t)nq_max * 16, 256);
     const size_t inl_b = inlier_matches ? align_up((size_t)match_capacity * sizeof(sfm_gpu_dmatch), 256) : 0;
-    SFM_HIP(ctx, ctx->partial.reserve(partial_b * group));
     SFM_HIP(ctx, ctx->out.reserve(out_b * group));
     SFM_HIP(ctx, ctx->counts.reserve(cnt_b * group));
     SFM_HIP(ctx, ctx->redo.reserve(redo_b * group));
@@ -459,6 +460,10 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, const in
         pds.assign(g, PairDev());
         probs.assign(g, proto);
         const KnnPlan plan = plan_knn(nq_max, nt_max, g, ctx->knn_variant);
+        // a smaller (last) group may be planned with more train parts per job: size
+        // the record buffer from this group's own plan
+        const size_t partial_b = align_up((size_t)plan.n_splits * qalloc_max * sizeof(uint4), 256);
+        SFM_HIP(ctx, ctx->partial.reserve(partial_b * g));
         for (int i = 0; i < g; ++i) {
             const ImageDev& q = images[pairs[2 * (g0 + i)]]->d;
             const ImageDev& t = images[pairs[2 * (g0 + i) + 1]]->d;

@@ -257,7 +257,7 @@ def match_pairs(ctx, images, pairs, K, ratio=0.7, model=MODEL_ESSENTIAL, mode=RA
     if want_matches:
         cap = max([images[i].n for i in pairs[:, 0]] + [1])
         out = np.zeros((n_pairs, cap), dtype=DMATCH_DTYPE)
-    ctx.check(ctx._L.sfm_gpu_match_pairs(ctx.handle, arr, ptr(pairs), n_pairs, ctypes.byref(p),
+    ctx.check(ctx._L.sfm_gpu_match_pairs(ctx.handle, arr, len(images), ptr(pairs), n_pairs, ctypes.byref(p),
                                          ptr(n_good), ptr(n_inl), ptr(out), cap))
     if want_matches:
         return n_good, n_inl, [out[i, :n_inl[i]].copy() for i in range(n_pairs)]

@@ -143,3 +143,31 @@ def test_allpairs_driver_single_process_equals_match_pairs(gpu_ctx):
     assert good.sum() == ng.sum() and inl.sum() == ni.sum() and ng.sum() > 0
     for im in owned:
         im.close()
+
+
+def test_match_pairs_many_small_pairs_in_two_groups_and_bad_index(gpu_ctx):
+    """More pairs than one launch group holds (256): the last, smaller group is
+    planned differently and must give the same answers as pair-by-pair calls."""
+    from sfm_amd import _lib
+    rng = np.random.default_rng(31)
+    pool = synth.sift_like(600, 51)
+    images = []
+    for v in range(12):
+        n = 300 + 17 * v
+        d = np.clip(pool[rng.permutation(600)[:n]] + rng.integers(-3, 4, (n, 128)), 0, 255).astype(np.float32)
+        kp = np.stack([rng.uniform(0, synth.IMG_W, n), rng.uniform(0, synth.IMG_H, n)], 1).astype(np.float32)
+        images.append(matcher.Image(gpu_ctx, d, kp))
+    pairs = np.array([[i, j] for i in range(12) for j in range(12) if i != j] * 2, np.int32)[:261]
+    kw = dict(ratio=0.8, model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED, prob=0.99,
+              threshold=3.0, n_hyp=32)
+    ng, ni, sel = matcher.match_pairs(gpu_ctx, images, pairs, None, want_matches=True, **kw)
+    for p in (0, 100, 255, 256, 260):
+        g1, i1, s1 = matcher.match_pairs(gpu_ctx, images, pairs[p:p + 1], None, want_matches=True, **kw)
+        assert g1[0] == ng[p] and i1[0] == ni[p]
+        assert (s1[0] == sel[p]).all()
+    assert ng.sum() > 0
+    with pytest.raises(_lib.SfmGpuError) as e:
+        matcher.match_pairs(gpu_ctx, images, np.array([[0, 12]], np.int32), None, **kw)
+    assert e.value.code == _lib.ERR_ARG
+    for im in images:
+        im.close()
