@@ -167,10 +167,16 @@ def _near_threshold_problem(model, seed, n_clean, n_edge, thr_px):
     return p1, p2, table
 
 
-@pytest.mark.parametrize("model", [0, 1])
-def test_scoring_filter_is_exact_on_near_threshold_points(gpu_ctx, oracle, model):
+@pytest.mark.parametrize("model,coord_scale", [(0, 1.0), (1, 1.0), (1, 64.0), (1, 1.0 / 64.0)])
+def test_scoring_filter_is_exact_on_near_threshold_points(gpu_ctx, oracle, model, coord_scale):
     thr = 1.0 if model == 0 else 3.0
     p1, p2, table = _near_threshold_problem(model, 77 + model, 1500, 4500, thr)
+    if coord_scale != 1.0:
+        # the same geometry in other units (the filter's error bound scales with
+        # the largest coordinate): pixels and threshold scaled alike
+        p1 = (p1 * coord_scale).astype(np.float32).astype(np.float64)
+        p2 = (p2 * coord_scale).astype(np.float32).astype(np.float64)
+        thr = thr * coord_scale
     K = synth.REF_K if model == 0 else None
     o = oracle.ransac(p1, p2, K, model=model, prob=0.99, threshold=thr, fixed_count=len(table),
                       sample_table=table, want_counts=True)
