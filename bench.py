@@ -31,13 +31,13 @@ sys.path.insert(0, ROOT)
 INT8_DENSE_PEAK_TOPS = 5000.0  # MI355X dense int8 MFMA: 2x the bf16 rate (~2.5 PF)
 
 
-def make_pairs(n_pairs, n_desc, seed0):
+def make_pairs(n_pairs, n_desc, seed0, wrong_frac=0.0):
     from sfm_amd import synth
     descs, kps = [], []
     for p in range(n_pairs):
         s = seed0 + 10 * p
         Q, T, planted = synth.planted_pair(n_desc, n_desc, s + 1, s + 2, s + 3)
-        kq, kt = synth.keypoints_for_pair(n_desc, n_desc, planted, s + 4)
+        kq, kt = synth.keypoints_for_pair(n_desc, n_desc, planted, s + 4, wrong_frac=wrong_frac)
         descs += [Q, T]
         kps += [kq, kt]
     return descs, kps
@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--n-desc", type=int, default=8192)
     ap.add_argument("--hyps", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wrong-frac", type=float, default=0.07,
+                    help="share of descriptor matches that are geometrically wrong (reference log: 4-11 %%)")
     ap.add_argument("--no-microkernel", action="store_true", help="skip the MFMA-only ceiling launches")
     ap.add_argument("--knn-variant", type=int, default=-1, help="debug: force the sweep kernel shape")
     ap.add_argument("--score-filter", type=int, default=1, help="debug: 0 = double precision only")
@@ -96,7 +98,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     B, n, nh = args.pairs_per_step, args.n_desc, args.hyps
-    descs, kps = make_pairs(B, n, 1000 + 100000 * rank)
+    descs, kps = make_pairs(B, n, 1000 + 100000 * rank, args.wrong_frac)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         d_desc = torch.from_numpy(np.stack(descs)).cuda()          # [2B, n, 128] float32

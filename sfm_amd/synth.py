@@ -91,9 +91,12 @@ def two_view(n, seed, inlier_frac=0.9, noise_px=0.5, K=REF_K):
     return pts1, pts2, is_in, E
 
 
-def keypoints_for_pair(n_query, n_train, planted, seed, noise_px=0.5, K=REF_K):
+def keypoints_for_pair(n_query, n_train, planted, seed, noise_px=0.5, K=REF_K, wrong_frac=0.0):
     """Keypoint coordinates (float32 n x 2) for both images of a planted pair:
-    planted rows are projections of common 3-D points, the rest are random."""
+    planted rows are projections of common 3-D points, the rest are random.
+    `wrong_frac` of the planted descriptor matches keep a random train keypoint:
+    matches that pass the ratio test but not the geometry (the reference's own
+    log, info.txt:23-44, has 89-96 % of the ratio-test survivors as inliers)."""
     rng = np.random.default_rng(seed)
     kq = np.stack([rng.uniform(0, IMG_W, n_query), rng.uniform(0, IMG_H, n_query)], 1)
     kt = np.stack([rng.uniform(0, IMG_W, n_train), rng.uniform(0, IMG_H, n_train)], 1)
@@ -109,5 +112,10 @@ def keypoints_for_pair(n_query, n_train, planted, seed, noise_px=0.5, K=REF_K):
     p2 = (X @ R.T + t) @ K.T
     p2 = p2[:, :2] / p2[:, 2:]
     kq[rows] += rng.normal(0, noise_px, (len(rows), 2))
-    kt[planted[rows]] = p2 + rng.normal(0, noise_px, (len(rows), 2))
+    p2 = p2 + rng.normal(0, noise_px, (len(rows), 2))
+    if wrong_frac > 0.0:
+        right = np.random.default_rng(seed + 7919).uniform(size=len(rows)) >= wrong_frac
+        kt[planted[rows[right]]] = p2[right]
+    else:
+        kt[planted[rows]] = p2
     return kq.astype(np.float32), kt.astype(np.float32)
