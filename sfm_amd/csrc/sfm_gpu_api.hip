@@ -53,8 +53,19 @@ int prepare_image(sfm_gpu_ctx* ctx, ImageStore& st, DevBuf& raw, const void* des
     size_t src_step = step;
     if (!on_device && n > 0) {
         SFM_HIP(ctx, raw.reserve((size_t)n * rowbytes));
-        SFM_HIP(ctx, hipMemcpy2DAsync(raw.p, rowbytes, desc, step, rowbytes, n, hipMemcpyHostToDevice,
-                                      ctx->stream));
+        if (step == rowbytes) {
+            SFM_HIP(ctx, hipMemcpyAsync(raw.p, desc, (size_t)n * rowbytes, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            // strided cv::Mat: gather the rows on the host into pinned memory first (a
+            // pitched copy from pageable memory goes row by row and is far slower)
+            SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still be in flight
+            SFM_HIP(ctx, ctx->pin_b.reserve((size_t)n * rowbytes));
+            for (int r = 0; r < n; ++r)
+                std::memcpy(ctx->pin_b.as<char>() + (size_t)r * rowbytes, (const char*)desc + (size_t)r * step,
+                            rowbytes);
+            SFM_HIP(ctx, hipMemcpyAsync(raw.p, ctx->pin_b.p, (size_t)n * rowbytes, hipMemcpyHostToDevice,
+                                        ctx->stream));
+        }
         src = raw.p;
         src_step = rowbytes;
     }
