@@ -42,6 +42,24 @@ int run_prep_jobs(sfm_gpu_ctx* ctx, const std::vector<PrepJob>& jobs, int dtype,
     return SFM_GPU_OK;
 }
 
+// Host rows -> contiguous device rows in `raw`.  A pitched copy from pageable
+// memory goes row by row and is far slower than one flat copy, so strided input
+// (cv::Mat with step > row bytes) is first gathered into pinned memory.
+int upload_rows(sfm_gpu_ctx* ctx, DevBuf& raw, const void* desc, int n, size_t step, size_t rowbytes)
+{
+    SFM_HIP(ctx, raw.reserve((size_t)n * rowbytes));
+    if (step == rowbytes) {
+        SFM_HIP(ctx, hipMemcpyAsync(raw.p, desc, (size_t)n * rowbytes, hipMemcpyHostToDevice, ctx->stream));
+        return SFM_GPU_OK;
+    }
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still be in flight
+    SFM_HIP(ctx, ctx->pin_b.reserve((size_t)n * rowbytes));
+    for (int r = 0; r < n; ++r)
+        std::memcpy(ctx->pin_b.as<char>() + (size_t)r * rowbytes, (const char*)desc + (size_t)r * step, rowbytes);
+    SFM_HIP(ctx, hipMemcpyAsync(raw.p, ctx->pin_b.p, (size_t)n * rowbytes, hipMemcpyHostToDevice, ctx->stream));
+    return SFM_GPU_OK;
+}
+
 // Uploads (or reads in place) n rows and runs the preparation kernel into st.
 int prepare_image(sfm_gpu_ctx* ctx, ImageStore& st, DevBuf& raw, const void* desc, int n,
                   size_t step, int dtype, bool on_device, bool with_kp)
@@ -52,20 +70,8 @@ int prepare_image(sfm_gpu_ctx* ctx, ImageStore& st, DevBuf& raw, const void* des
     const void* src = desc;
     size_t src_step = step;
     if (!on_device && n > 0) {
-        SFM_HIP(ctx, raw.reserve((size_t)n * rowbytes));
-        if (step == rowbytes) {
-            SFM_HIP(ctx, hipMemcpyAsync(raw.p, desc, (size_t)n * rowbytes, hipMemcpyHostToDevice, ctx->stream));
-        } else {
-            // strided cv::Mat: gather the rows on the host into pinned memory first (a
-            // pitched copy from pageable memory goes row by row and is far slower)
-            SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still be in flight
-            SFM_HIP(ctx, ctx->pin_b.reserve((size_t)n * rowbytes));
-            for (int r = 0; r < n; ++r)
-                std::memcpy(ctx->pin_b.as<char>() + (size_t)r * rowbytes, (const char*)desc + (size_t)r * step,
-                            rowbytes);
-            SFM_HIP(ctx, hipMemcpyAsync(raw.p, ctx->pin_b.p, (size_t)n * rowbytes, hipMemcpyHostToDevice,
-                                        ctx->stream));
-        }
+        const int urc = upload_rows(ctx, raw, desc, n, step, rowbytes);
+        if (urc) return urc;
         src = raw.p;
         src_step = rowbytes;
     }
@@ -324,9 +330,8 @@ int sfm_gpu_image_prepare_into(sfm_gpu_ctx* ctx, const void* desc, int n, size_t
     if (!desc_on_device && n > 0) {
         // staging buffer is reused: wait for earlier users of it
         SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        SFM_HIP(ctx, ctx->raw_q.reserve((size_t)n * rowbytes));
-        SFM_HIP(ctx, hipMemcpy2DAsync(ctx->raw_q.p, rowbytes, desc, step, rowbytes, n,
-                                      hipMemcpyHostToDevice, ctx->stream));
+        rc = upload_rows(ctx, ctx->raw_q, desc, n, step, rowbytes);
+        if (rc) return rc;
         src = ctx->raw_q.p;
         src_step = rowbytes;
     }
