@@ -1124,14 +1124,26 @@ KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant
     const int t_chunks = (n_train_max + CHUNK - 1) / CHUNK;
     const long long qblocks = (long long)((n_query_max + p.q_per_block - 1) / p.q_per_block) * n_jobs;
     // The sweep carries no data-dependent state between tiles, so the train rows
-    // can be split freely: enough parts to give every CU a workgroup, and
-    // never more than MAX_SWEEP_CHUNKS chunks per part.
-    int splits = (t_chunks + MAX_SWEEP_CHUNKS - 1) / MAX_SWEEP_CHUNKS;
-    if (splits < 1) splits = 1;
-    // two resident workgroups per CU for the 4-wave shapes, one for the 8-wave ones
-    const long long want = (p.variant == 0 || p.variant == 1 || p.variant == 4) ? 512 : 256;
-    while (qblocks * splits < want && splits * 2 <= t_chunks && t_chunks / (splits * 2) >= 2)
-        splits *= 2;
+    // can be split freely into parts (never more than MAX_SWEEP_CHUNKS chunks
+    // each).  The number of parts is chosen to minimise
+    //     rounds of resident workgroups x (chunks per part + 1 for set-up),
+    // with `slots` workgroups resident at a time (two per CU for the 4-wave
+    // shapes, one for the 8-wave ones); ties go to fewer parts (fewer records).
+    const long long slots = (p.variant == 0 || p.variant == 1 || p.variant == 4) ? 512 : 256;
+    const int s_min = std::max(1, (t_chunks + MAX_SWEEP_CHUNKS - 1) / MAX_SWEEP_CHUNKS);
+    const int s_max = std::max(s_min, std::min(t_chunks, 64));
+    int splits = s_min;
+    long long best_cost = -1;
+    for (int sp = s_min; sp <= s_max && t_chunks > 0; ++sp) {
+        const long long cps = (t_chunks + sp - 1) / sp;
+        const long long parts = (t_chunks + cps - 1) / cps;  // what the launch will really use
+        const long long rounds = (qblocks * parts + slots - 1) / slots;
+        const long long cost = rounds * (cps + 1);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            splits = sp;
+        }
+    }
     p.n_splits = splits;
     p.chunks_per_split = (t_chunks + splits - 1) / splits;
     if (p.chunks_per_split < 1) p.chunks_per_split = 1;
