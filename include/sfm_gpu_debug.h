@@ -38,6 +38,10 @@ int sfm_gpu_debug_mfma16_probe(sfm_gpu_ctx* ctx, const int8_t* a, const int8_t* 
 int sfm_gpu_debug_ransac_dump(sfm_gpu_ctx* ctx, int n_hyp, int32_t* table, int32_t* nmodels,
                               int32_t* counts, double* models);
 
+/* Counts the integers n < 2^24 for which the device's plain sqrtf((float)n)
+ * differs from the correctly rounded value the match records carry. */
+int sfm_gpu_debug_sqrt_probe(sfm_gpu_ctx* ctx, int32_t* mismatches);
+
 /* 0: the RANSAC scoring kernel evaluates every (model, point) pair in double
  * precision only; 1 (default): a float32 filter with a rigorous error bound
  * settles the clear cases first.  Both give identical counts; the switch lets

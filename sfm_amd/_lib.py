@@ -92,6 +92,7 @@ def lib():
     L.sfm_gpu_debug_redo_count.argtypes = [vp, vp]
     L.sfm_gpu_debug_mfma_probe.argtypes = [vp, vp, vp, vp]
     L.sfm_gpu_debug_mfma16_probe.argtypes = [vp, vp, vp, vp]
+    L.sfm_gpu_debug_sqrt_probe.argtypes = [vp, vp]
     L.sfm_gpu_debug_ransac_dump.argtypes = [vp, c.c_int, vp, vp, vp, vp]
     L.sfm_gpu_debug_set_score_filter.argtypes = [c.c_int]
     _lib = L

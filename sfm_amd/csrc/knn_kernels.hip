@@ -741,6 +741,12 @@ __device__ __forceinline__ float sqrt_exact_u32(uint32_t n)
     return f;
 }
 
+// Float distance of a squared distance n < 2^24 as the match records carry it:
+// the correctly rounded square root.  The device's sqrtf is correctly rounded
+// on every such n (a test counts the differences from sqrt_exact_u32 over all
+// 2^24 of them and requires zero), and costs a quarter of the checked form.
+__device__ __forceinline__ float sqrt_d2(uint32_t n) { return sqrtf((float)n); }
+
 typedef unsigned long long u64;
 
 // keeps the three smallest of (a1<=a2<=a3) and v
@@ -912,7 +918,7 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
         m.imgIdx = 0;
         if (ej != 0xFFFFFFFFu) {
             m.trainIdx = l == 0 ? row1 : row2;
-            m.distance = sqrt_exact_u32(ej >> 5);
+            m.distance = sqrt_d2(ej >> 5);
         } else {
             m.trainIdx = -1;
             m.distance = __uint_as_float(0x7f7fffffu);  // FLT_MAX
@@ -1003,7 +1009,7 @@ knn_redo_scan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int max_seg)
                 // rows come in ascending order, so a later row needs a float distance
                 // strictly below the second best's, hence a smaller d2
                 if (ok && sg == 0 && d2 < lim) {
-                    const u64 key = ((u64)__float_as_uint(sqrt_exact_u32((uint32_t)d2)) << 32) | (uint32_t)row;
+                    const u64 key = ((u64)__float_as_uint(sqrt_d2((uint32_t)d2)) << 32) | (uint32_t)row;
                     if (key < f) { s = f; f = key; lim = d2f; d2f = d2; }
                     else if (key < s) { s = key; lim = d2; }
                 }
@@ -1076,6 +1082,17 @@ __global__ void __launch_bounds__(64) mfma_layout_probe_kernel(const int8_t* A, 
         const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
         C[row * 32 + col] = c[i];
     }
+}
+
+// Counts the integers n in [0, 2^24) for which plain sqrtf((float)n) differs
+// from the verified correctly rounded value (test hook).
+__global__ void __launch_bounds__(256) sqrt_probe_kernel(int32_t* mismatches)
+{
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= (1u << 24)) return;
+    const float a = sqrtf((float)n);
+    const float b = sqrt_exact_u32(n);
+    if (__float_as_uint(a) != __float_as_uint(b)) atomicAdd(mismatches, 1);
 }
 
 // C(16x16) = A(16 rows x 64 k) * B^T (B given as [16 cols][64 k]) through one
@@ -1220,6 +1237,11 @@ hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, in
 hipError_t launch_mfma_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c)
 {
     hipLaunchKernelGGL(mfma_layout_probe_kernel, dim3(1), dim3(64), 0, s, a, b, c);
+    return hipGetLastError();
+}
+hipError_t launch_sqrt_probe(hipStream_t s, int32_t* mismatches)
+{
+    hipLaunchKernelGGL(sqrt_probe_kernel, dim3((1u << 24) / 256), dim3(256), 0, s, mismatches);
     return hipGetLastError();
 }
 hipError_t launch_mfma16_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c)

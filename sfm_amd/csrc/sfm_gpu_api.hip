@@ -487,6 +487,20 @@ int sfm_gpu_debug_mfma_probe(sfm_gpu_ctx* ctx, const int8_t* a, const int8_t* b,
     return SFM_GPU_OK;
 }
 
+// Number of integers n < 2^24 whose plain device sqrtf differs from the
+// correctly rounded float square root.
+int sfm_gpu_debug_sqrt_probe(sfm_gpu_ctx* ctx, int32_t* mismatches)
+{
+    if (!ctx || !mismatches) return SFM_GPU_ERR_ARG;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, ctx->rs_misc.reserve(256));
+    SFM_HIP(ctx, hipMemsetAsync(ctx->rs_misc.p, 0, 4, ctx->stream));
+    SFM_HIP(ctx, launch_sqrt_probe(ctx->stream, ctx->rs_misc.as<int32_t>()));
+    SFM_HIP(ctx, hipMemcpyAsync(mismatches, ctx->rs_misc.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFM_GPU_OK;
+}
+
 // c[16][16] = a[16][64] * b^T, b given as [16 columns][64 k]; host pointers.
 int sfm_gpu_debug_mfma16_probe(sfm_gpu_ctx* ctx, const int8_t* a, const int8_t* b, int32_t* c)
 {

@@ -103,6 +103,7 @@ hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs
                                int n_splits, int k, int group_mode);
 hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_splits, int k);
 hipError_t launch_mfma_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c);
+hipError_t launch_sqrt_probe(hipStream_t s, int32_t* mismatches);
 hipError_t launch_mfma16_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c);
 
 }  // namespace sfm

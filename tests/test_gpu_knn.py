@@ -33,6 +33,14 @@ def test_mfma_operand_and_accumulator_layout(gpu_ctx):
     assert (c == ref).all()
 
 
+def test_device_sqrtf_is_correctly_rounded_on_all_squared_distances(gpu_ctx):
+    # the match records take their float distance from the device's sqrtf; this
+    # pins that it equals the correctly rounded root for every integer < 2^24
+    m = np.zeros(1, np.int32)
+    gpu_ctx.check(gpu_ctx._L.sfm_gpu_debug_sqrt_probe(gpu_ctx.handle, matcher.ptr(m)))
+    assert m[0] == 0
+
+
 def test_mfma16_operand_and_accumulator_layout(gpu_ctx):
     rng = np.random.default_rng(1)
     a = rng.integers(-128, 128, (16, 64)).astype(np.int8)
