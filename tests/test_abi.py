@@ -59,3 +59,34 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in text and "sfm_oracle" not in text, f
+
+
+def test_headers_are_plain_c_and_a_c_host_links(tmp_path):
+    """The boundary is for a compiled host: both headers must be valid C99 and
+    C++17, and a C program must link against the library and call it (entry
+    points that need no GPU)."""
+    import subprocess
+    from sfm_amd import _lib
+    inc = os.path.join(ROOT, "include")
+    src = tmp_path / "host.c"
+    src.write_text(
+        '#include "sfm_gpu.h"\n#include "sfm_gpu_debug.h"\n#include <stdio.h>\n#include <string.h>\n'
+        "int main(void) {\n"
+        "    sfm_gpu_dmatch m; sfm_gpu_match_params p; memset(&p, 0, sizeof p); (void)m;\n"
+        "    if (sizeof(sfm_gpu_dmatch) != 16) return 2;            /* cv::DMatch layout */\n"
+        "    if (!strstr(sfm_gpu_version(), \"gfx950\")) return 3;\n"
+        "    if (sfm_gpu_image_packed_bytes(1) != 1024u * (128 + 4 + 4 + 8)) return 4;\n"
+        "    if (sfm_gpu_create(0, 0, 0) != SFM_GPU_ERR_ARG) return 5; /* null out pointer */\n"
+        "    { int32_t keep[2], n = -1; sfm_gpu_dmatch r[4]; int32_t c[2] = {2, 1};\n"
+        "      memset(r, 0, sizeof r); r[0].distance = 1.f; r[1].distance = 2.f; r[2].distance = 1.f; r[3].distance = 1.f;\n"
+        "      if (sfm_gpu_ratio_test(r, c, 2, 2, 0.7, keep, &n) != SFM_GPU_OK || n != 1 || keep[0] != 0) return 6; }\n"
+        '    puts("c host ok");\n    return 0;\n}\n')
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe),
+                           "-L", libdir, "-lsfm_gpu", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "c host ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+    cpp = tmp_path / "host.cpp"
+    cpp.write_text('#include "sfm_gpu.h"\n#include "sfm_gpu_debug.h"\nint main() { return sfm_gpu_version() ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(cpp)])
