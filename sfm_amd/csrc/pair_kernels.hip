@@ -1,6 +1,8 @@
 // Glue between the k-NN output and RANSAC for one image pair, on the device:
 // the ratio test with point gathering (/root/reference/main.cpp:187-198) and
 // the final inlier selection (/root/reference/main.cpp:225-231).
+#include <algorithm>
+
 #include "ransac_dev.h"
 
 namespace sfm {
@@ -29,36 +31,54 @@ __device__ __forceinline__ int compact_slot(bool flag, int* wsum, int* base)
     return flag ? b + wave_prefix + lane_prefix : -1;
 }
 
+// Ratio test verdict of query row q.
+__device__ __forceinline__ bool ratio_keep(const PairDev& pd, int q, double ratio)
+{
+    if (pd.counts[q] < 2) return false;
+    return (double)pd.knn[2 * q].distance < ratio * (double)pd.knn[2 * q + 1].distance;
+}
+
+// Ratio test and gather; grid = (tiles of 1024 query rows, pairs).  A workgroup
+// compacts its own tile; the slot of its first survivor is the number of
+// survivors in the tiles before it, which it simply counts again itself (reads
+// that hit L2, no communication between workgroups, deterministic order).
 __global__ void __launch_bounds__(1024) ratio_compact_kernel(const PairDev* __restrict__ pairs, double ratio)
 {
     __shared__ int wsum[16];
     __shared__ int base;
-    const PairDev pd = pairs[blockIdx.x];
-    if (threadIdx.x == 0) base = 0;
+    const PairDev pd = pairs[blockIdx.y];
+    const int tile = blockIdx.x;
+    const int n_tiles = (pd.n_query + 1023) / 1024;
+    if (tile >= n_tiles && !(tile == 0 && n_tiles == 0)) return;
+    const int tid = threadIdx.x;
+    int before = 0;
+    for (int j = 0; j < tile; ++j) before += ratio_keep(pd, j * 1024 + tid, ratio) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    if ((tid & 63) == 0) wsum[tid >> 6] = before;
     __syncthreads();
-    for (int start = 0; start < pd.n_query; start += 1024) {
-        const int q = start + threadIdx.x;
-        bool flag = false;
-        sfm_gpu_dmatch m0;
-        if (q < pd.n_query && pd.counts[q] >= 2) {
-            m0 = pd.knn[2 * q];
-            const sfm_gpu_dmatch m1 = pd.knn[2 * q + 1];
-            flag = (double)m0.distance < ratio * (double)m1.distance;
-        }
-        const int slot = compact_slot(flag, wsum, &base);
-        if (slot >= 0) {
-            pd.good[slot] = m0;
-            if (pd.kp_q && pd.kp_t) {
-                const float2 a = pd.kp_q[m0.queryIdx];
-                const float2 b = pd.kp_t[m0.trainIdx];
-                pd.px1[2 * slot] = (double)a.x;
-                pd.px1[2 * slot + 1] = (double)a.y;
-                pd.px2[2 * slot] = (double)b.x;
-                pd.px2[2 * slot + 1] = (double)b.y;
-            }
+    if (tid == 0) {
+        int sum = 0;
+        for (int w = 0; w < 16; ++w) sum += wsum[w];
+        base = sum;
+    }
+    __syncthreads();
+    const int q = tile * 1024 + tid;
+    const bool flag = q < pd.n_query && ratio_keep(pd, q, ratio);
+    const int slot = compact_slot(flag, wsum, &base);
+    if (slot >= 0) {
+        const sfm_gpu_dmatch m0 = pd.knn[2 * q];
+        pd.good[slot] = m0;
+        if (pd.kp_q && pd.kp_t) {
+            const float2 a = pd.kp_q[m0.queryIdx];
+            const float2 b = pd.kp_t[m0.trainIdx];
+            pd.px1[2 * slot] = (double)a.x;
+            pd.px1[2 * slot + 1] = (double)a.y;
+            pd.px2[2 * slot] = (double)b.x;
+            pd.px2[2 * slot + 1] = (double)b.y;
         }
     }
-    if (threadIdx.x == 0) *pd.n_good = base;
+    if (tid == 0 && (tile == n_tiles - 1 || n_tiles == 0)) *pd.n_good = base;
 }
 
 __global__ void __launch_bounds__(1024) inlier_compact_kernel(const PairDev* __restrict__ pairs)
@@ -83,9 +103,10 @@ __global__ void __launch_bounds__(1024) inlier_compact_kernel(const PairDev* __r
 
 }  // namespace
 
-hipError_t launch_ratio_compact(hipStream_t s, const PairDev* pairs, int n_pairs, double ratio)
+hipError_t launch_ratio_compact(hipStream_t s, const PairDev* pairs, int n_pairs, int n_query_max, double ratio)
 {
-    hipLaunchKernelGGL(ratio_compact_kernel, dim3(n_pairs), dim3(1024), 0, s, pairs, ratio);
+    const int tiles = std::max(1, (n_query_max + 1023) / 1024);
+    hipLaunchKernelGGL(ratio_compact_kernel, dim3(tiles, n_pairs), dim3(1024), 0, s, pairs, ratio);
     return hipGetLastError();
 }
 

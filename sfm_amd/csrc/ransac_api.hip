@@ -523,7 +523,7 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
         }
         {
             ProfScope ps(ctx, "ratio_compact");
-            SFM_HIP(ctx, launch_ratio_compact(s, dpds, g, params->ratio));
+            SFM_HIP(ctx, launch_ratio_compact(s, dpds, g, nq_max, params->ratio));
         }
         rc = ransac_batch(ctx, probs, nq_max, hyp_cap, rp, nullptr, results, false);
         if (rc) return rc;

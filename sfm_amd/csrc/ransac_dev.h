@@ -78,7 +78,7 @@ struct PairDev {
     int32_t capacity;
 };
 
-hipError_t launch_ratio_compact(hipStream_t s, const PairDev* pairs, int n_pairs, double ratio);
+hipError_t launch_ratio_compact(hipStream_t s, const PairDev* pairs, int n_pairs, int n_query_max, double ratio);
 hipError_t launch_inlier_compact(hipStream_t s, const PairDev* pairs, int n_pairs);
 
 }  // namespace sfm
