@@ -1094,7 +1094,7 @@ __global__ void __launch_bounds__(256) ransac_table_fixed_kernel(const RansacPro
                 if (j == i) { idx[i] = v; break; }
             }
         }
-        ok = !(check && subset_collinear(pb, idx, m));
+        ok = !(check && subset_collinear7(pb, idx));  // check implies m == 7
     }
     if (!ok) idx[0] = -1;
     for (int k = 0; k < m; ++k) pb.table[(size_t)r * m + k] = idx[k];
