@@ -136,6 +136,31 @@ int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int
                    int mode, const int32_t* sample_table, int n_hyp, uint8_t* mask,
                    double* model_out, int32_t* n_inliers, int32_t* iters_used, int32_t* ok);
 
+/* ---- pose recovery: replaces main.cpp:420 ----------------------------- */
+
+/*
+ * recoverPose(EssentialMat, pointsL, pointsR, K, R, T)            main.cpp:420
+ * (and bundle_adjustment.h:80): decomposes E into its four (R, t) candidates
+ * and keeps the one that puts the most correspondences in front of both
+ * cameras at a depth below distance_thresh (in units of the baseline).
+ *
+ *   E             host, 9 doubles row-major, on normalised coordinates (the
+ *                 output of sfm_gpu_ransac with model = ESSENTIAL)
+ *   pts1, pts2    host, n x 2 doubles, pixel coordinates
+ *   K             host, 3x3 row-major camera matrix
+ *   distance_thresh   OpenCV's default is 50.0 (the reference passes none)
+ *   R_out, t_out  out, 9 and 3 doubles: x2 ~ R x1 + t, |t| = 1
+ *   mask          optional, n bytes, in/out as in OpenCV: rows holding 0 do
+ *                 not vote; on return 1 marks the correspondences that pass
+ *                 the test under the chosen pose.  NULL: every row votes.
+ *   n_good        out, optional: recoverPose's return value (the vote count)
+ * Ties between candidates resolve in OpenCV's order (R1,t) (R2,t) (R1,-t)
+ * (R2,-t).  SFM_GPU_ERR_ARG when E has fewer than two non-zero singular values.
+ */
+int sfm_gpu_recover_pose(sfm_gpu_ctx* ctx, const double* E, const double* pts1,
+                         const double* pts2, int n, const double* K, double distance_thresh,
+                         double* R_out, double* t_out, uint8_t* mask, int32_t* n_good);
+
 /* ---- device-resident images: the all-pairs driver --------------------- */
 
 /*
@@ -230,7 +255,7 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
  * query returns accumulated milliseconds and launch count since the last
  * reset.  Kernel names: "knn2_mfma", "prep_rows", "knn_finalize",
  * "ratio_compact", "ransac_table", "ransac_solve", "ransac_score",
- * "ransac_select".  Has no counterpart in the reference.
+ * "ransac_select", "pose_vote".  Has no counterpart in the reference.
  */
 int sfm_gpu_profile_enable(sfm_gpu_ctx* ctx, int on);
 /* Restricts the timing to one named kernel (NULL: all of them), so that a

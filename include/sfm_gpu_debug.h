@@ -48,6 +48,10 @@ int sfm_gpu_debug_sqrt_probe(sfm_gpu_ctx* ctx, int32_t* mismatches);
  * tests prove it.  Process-wide. */
 int sfm_gpu_debug_set_score_filter(int on);
 
+/* Vote counts of the four pose candidates in the last sfm_gpu_recover_pose call
+ * on this context, in the order (R1,t) (R2,t) (R1,-t) (R2,-t). */
+int sfm_gpu_debug_pose_votes(sfm_gpu_ctx* ctx, int32_t* votes4);
+
 #ifdef __cplusplus
 }
 #endif

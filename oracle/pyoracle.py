@@ -59,6 +59,12 @@ def lib():
         L.oracle_ransac.argtypes = [c.c_int, vp, vp, c.c_int, vp, c.c_double, c.c_double,
                                     c.c_int, c.c_int, vp, vp, vp, vp, vp, vp]
         L.oracle_ransac.restype = c.c_int
+        L.oracle_svd3.argtypes = [vp, vp, vp, vp]
+        L.oracle_svd3.restype = c.c_int
+        L.oracle_decompose_essential.argtypes = [vp, vp, vp, vp]
+        L.oracle_decompose_essential.restype = c.c_int
+        L.oracle_recover_pose.argtypes = [vp, vp, vp, c.c_int, vp, c.c_double, vp, vp, vp, vp]
+        L.oracle_recover_pose.restype = c.c_int
         _lib = L
     return _lib
 
@@ -209,3 +215,32 @@ def ransac(pts1, pts2, K=None, model=MODEL_ESSENTIAL, prob=0.99, threshold=1.0, 
                              ctypes.byref(n_inl), ctypes.byref(iters), _p(counts))
     return dict(ok=ok, mask=mask, model=model_out, n_inliers=n_inl.value, iters=iters.value,
                 counts=counts)
+
+
+def svd3(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    U = np.zeros((3, 3)); S = np.zeros(3); V = np.zeros((3, 3))
+    ok = lib().oracle_svd3(_p(A), _p(U), _p(S), _p(V))
+    return ok, U, S, V
+
+
+def decompose_essential(E):
+    E = np.ascontiguousarray(E, dtype=np.float64)
+    R1 = np.zeros((3, 3)); R2 = np.zeros((3, 3)); t = np.zeros(3)
+    ok = lib().oracle_decompose_essential(_p(E), _p(R1), _p(R2), _p(t))
+    return ok, R1, R2, t
+
+
+def recover_pose(E, pts1, pts2, K, distance_thresh=50.0, mask=None):
+    """Returns dict(n_good, R, t, mask, votes); n_good = -1 on failure."""
+    E = np.ascontiguousarray(E, dtype=np.float64)
+    pts1 = np.ascontiguousarray(pts1, dtype=np.float64).reshape(-1, 2)
+    pts2 = np.ascontiguousarray(pts2, dtype=np.float64).reshape(-1, 2)
+    Kc = np.ascontiguousarray(K, dtype=np.float64)
+    n = pts1.shape[0]
+    R = np.zeros((3, 3)); t = np.zeros(3)
+    m = np.ones(n, dtype=np.uint8) if mask is None else np.array(mask, dtype=np.uint8)
+    votes = np.zeros(4, dtype=np.int32)
+    good = lib().oracle_recover_pose(_p(E), _p(pts1), _p(pts2), n, _p(Kc), distance_thresh,
+                                     _p(R), _p(t), _p(m), _p(votes))
+    return dict(n_good=good, R=R, t=t, mask=m, votes=votes)

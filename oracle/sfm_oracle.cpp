@@ -711,9 +711,174 @@ void symepi(const double* F, const float* m1, const float* m2, int n, float* err
     }
 }
 
+// ---- pose recovery -------------------------------------------------------
+// cv::recoverPose (called at /root/reference/main.cpp:420 and
+// /root/reference/bundle_adjustment.h:80) = cv::decomposeEssentialMat + a
+// cheirality vote of the four (R, t) candidates over the correspondences.
+// OpenCV's arithmetic (cv::SVD of E, one 4x4 SVD per triangulated point) is
+// not restated operation for operation; the restated semantics are: the same
+// four candidates in the same order, a point votes for a candidate when its
+// triangulated depth lies in (0, distance_thresh) in both cameras, the
+// candidate with the most votes wins with OpenCV's tie order.  The singular
+// vectors come from a one-sided Jacobi iteration, depths from the two-ray
+// least-squares (midpoint) triangulation.  PARITY UNPINNED like the rest.
+
+// A = U diag(S) V^T for a 3x3 row-major A, singular values descending, the
+// third left vector taken as u1 x u2 (so det U = +1 and a rank-2 input is
+// handled; S[2] is negative when that flips the vector).  Returns 0 when A has
+// rank < 2.
+int svd3_jacobi(const double* A, double* U, double* S, double* V)
+{
+    double G[9], W[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; i++) G[i] = A[i];
+    static const int PAIRS[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int sweep = 0; sweep < 30; sweep++) {
+        bool rotated = false;
+        for (int pi = 0; pi < 3; pi++) {
+            const int p = PAIRS[pi][0], q = PAIRS[pi][1];
+            const double alpha = (G[p] * G[p] + G[3 + p] * G[3 + p]) + G[6 + p] * G[6 + p];
+            const double beta = (G[q] * G[q] + G[3 + q] * G[3 + q]) + G[6 + q] * G[6 + q];
+            const double gamma = (G[p] * G[q] + G[3 + p] * G[3 + q]) + G[6 + p] * G[6 + q];
+            if (!(std::fabs(gamma) > 0x1p-52 * std::sqrt(alpha * beta))) continue;
+            rotated = true;
+            const double zeta = (beta - alpha) / (2.0 * gamma);
+            const double tt = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / std::sqrt(1.0 + tt * tt);
+            const double s = c * tt;
+            for (int i = 0; i < 3; i++) {
+                const double gp = G[3 * i + p], gq = G[3 * i + q];
+                G[3 * i + p] = c * gp - s * gq;
+                G[3 * i + q] = s * gp + c * gq;
+                const double wp = W[3 * i + p], wq = W[3 * i + q];
+                W[3 * i + p] = c * wp - s * wq;
+                W[3 * i + q] = s * wp + c * wq;
+            }
+        }
+        if (!rotated) break;
+    }
+    double sig[3];
+    for (int j = 0; j < 3; j++)
+        sig[j] = std::sqrt((G[j] * G[j] + G[3 + j] * G[3 + j]) + G[6 + j] * G[6 + j]);
+    int ord[3] = {0, 1, 2};
+    // stable descending order of three values
+    if (sig[ord[1]] > sig[ord[0]]) std::swap(ord[0], ord[1]);
+    if (sig[ord[2]] > sig[ord[1]]) std::swap(ord[1], ord[2]);
+    if (sig[ord[1]] > sig[ord[0]]) std::swap(ord[0], ord[1]);
+    if (!(sig[ord[1]] > 0x1p-40 * sig[ord[0]])) return 0;  // numerically rank < 2
+    for (int j = 0; j < 3; j++) {
+        S[j] = sig[ord[j]];
+        for (int i = 0; i < 3; i++) V[3 * i + j] = W[3 * i + ord[j]];
+    }
+    for (int j = 0; j < 2; j++)
+        for (int i = 0; i < 3; i++) U[3 * i + j] = G[3 * i + ord[j]] / S[j];
+    U[2] = U[3] * U[7] - U[6] * U[4];
+    U[5] = U[6] * U[1] - U[0] * U[7];
+    U[8] = U[0] * U[4] - U[3] * U[1];
+    // signed, so that the factorisation holds with det U = +1
+    S[2] = (U[2] * G[ord[2]] + U[5] * G[3 + ord[2]]) + U[8] * G[6 + ord[2]];
+    return 1;
+}
+
+double det3(const double* M)
+{
+    return (M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6])) +
+           M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// cv::decomposeEssentialMat: R1 = U W V^T, R2 = U W^T V^T, t = U[:,2] with
+// W = [0 1 0; -1 0 0; 0 0 1], after making det U and det V positive.
+int decompose_essential(const double* E, double* R1, double* R2, double* t)
+{
+    double U[9], S[3], V[9];
+    if (!svd3_jacobi(E, U, S, V)) return 0;
+    if (det3(V) < 0)
+        for (int i = 0; i < 9; i++) V[i] = -V[i];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) {
+            const double a = U[3 * i + 0] * V[3 * j + 1] - U[3 * i + 1] * V[3 * j + 0];
+            const double b = U[3 * i + 2] * V[3 * j + 2];
+            R1[3 * i + j] = a + b;
+            R2[3 * i + j] = b - a;
+        }
+        t[i] = U[3 * i + 2];
+    }
+    return 1;
+}
+
+// 1 when the two rays meet (in the least-squares sense) at depths inside
+// (0, dist) in both cameras.  a = R (x1, y1, 1), b = (x2, y2, 1); minimising
+// |z1 a + t - z2 b|^2 gives z1 = n1 / det, z2 = n2 / det with det >= 0.
+int cheirality_vote(const double* R, const double* t, double x1, double y1, double x2, double y2,
+                    double dist)
+{
+    const double a0 = (R[0] * x1 + R[1] * y1) + R[2];
+    const double a1 = (R[3] * x1 + R[4] * y1) + R[5];
+    const double a2 = (R[6] * x1 + R[7] * y1) + R[8];
+    const double aa = (a0 * a0 + a1 * a1) + a2 * a2;
+    const double bb = (x2 * x2 + y2 * y2) + 1.0;
+    const double ab = (a0 * x2 + a1 * y2) + a2;
+    const double at = (a0 * t[0] + a1 * t[1]) + a2 * t[2];
+    const double bt = (x2 * t[0] + y2 * t[1]) + t[2];
+    const double det = aa * bb - ab * ab;
+    const double n1 = ab * bt - at * bb;
+    const double n2 = aa * bt - ab * at;
+    const double lim = dist * det;
+    return det > 0 && n1 > 0 && n1 < lim && n2 > 0 && n2 < lim;
+}
+
 }  // namespace
 
 extern "C" {
+
+int oracle_svd3(const double* A, double* U, double* S, double* V) { return svd3_jacobi(A, U, S, V); }
+
+int oracle_decompose_essential(const double* E, double* R1, double* R2, double* t)
+{
+    return decompose_essential(E, R1, R2, t);
+}
+
+int oracle_recover_pose(const double* E, const double* pts1, const double* pts2, int n,
+                        const double* K, double distance_thresh, double* R_out, double* t_out,
+                        uint8_t* mask, int32_t* votes)
+{
+    if (!E || !K || n < 0 || (n > 0 && (!pts1 || !pts2)) || !R_out || !t_out) return -1;
+    double R1[9], R2[9], t[3], tneg[3];
+    if (!decompose_essential(E, R1, R2, t)) return -1;
+    for (int i = 0; i < 3; i++) tneg[i] = -t[i];
+    const double* Rc[4] = {R1, R2, R1, R2};
+    const double* tc[4] = {t, t, tneg, tneg};
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    std::vector<uint8_t> flags((size_t)n);
+    int good[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        uint8_t f = 0;
+        if (!mask || mask[i]) {
+            const double x1 = (pts1[2 * i] - cx) / fx, y1 = (pts1[2 * i + 1] - cy) / fy;
+            const double x2 = (pts2[2 * i] - cx) / fx, y2 = (pts2[2 * i + 1] - cy) / fy;
+            for (int k = 0; k < 4; k++)
+                if (cheirality_vote(Rc[k], tc[k], x1, y1, x2, y2, distance_thresh)) {
+                    f |= (uint8_t)(1 << k);
+                    good[k]++;
+                }
+        }
+        flags[i] = f;
+    }
+    // OpenCV's selection order: the first candidate that is >= all others.
+    int best = 3;
+    for (int k = 0; k < 4; k++) {
+        bool top = true;
+        for (int j = 0; j < 4; j++) top = top && good[k] >= good[j];
+        if (top) { best = k; break; }
+    }
+    for (int i = 0; i < 9; i++) R_out[i] = Rc[best][i];
+    for (int i = 0; i < 3; i++) t_out[i] = tc[best][i];
+    if (mask)
+        for (int i = 0; i < n; i++) mask[i] = (uint8_t)((flags[i] >> best) & 1);
+    if (votes)
+        for (int k = 0; k < 4; k++) votes[k] = good[k];
+    return good[best];
+}
+
 
 int oracle_knn_match(const float* query, int nq, size_t qstep, const float* train, int nt,
                      size_t tstep, int dim, int k, oracle_dmatch* out, int32_t* counts,

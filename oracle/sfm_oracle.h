@@ -6,6 +6,7 @@
  *     matcher->knnMatch(descL, descR, matches, 2)      /root/reference/main.cpp:184
  *     ratio test in double                              /root/reference/main.cpp:189-197
  *     findEssentialMat(..., FM_RANSAC, 0.99, 1.0, mask) /root/reference/main.cpp:224
+ *     recoverPose(E, ptsL, ptsR, K, R, t)               /root/reference/main.cpp:420
  *
  * The arithmetic of those calls lives in OpenCV 4.5.5 (pinned only by
  * /root/reference/README.md:5), which is NOT vendored in the reference and is
@@ -129,6 +130,28 @@ int oracle_ransac(int model_kind, const double* pts1, const double* pts2, int n,
                   int max_iters, int fixed_count, const int32_t* sample_table,
                   uint8_t* mask, double* model_out, int32_t* n_inliers,
                   int32_t* iters_used, int32_t* hyp_counts);
+
+/* 3x3 singular value decomposition A = U diag(S) V^T by one-sided Jacobi
+ * rotations (row-major, |S| descending, U[:,2] = U[:,0] x U[:,1] with S[2]
+ * carrying the sign).  Returns 1, or 0 when A has rank < 2. */
+int oracle_svd3(const double* A, double* U, double* S, double* V);
+
+/* cv::decomposeEssentialMat: the two rotations and the unit translation. */
+int oracle_decompose_essential(const double* E, double* R1, double* R2, double* t);
+
+/*
+ * cv::recoverPose(E, pts1, pts2, K, R, t, distanceThresh, mask)
+ * (/root/reference/main.cpp:420, /root/reference/bundle_adjustment.h:80 with
+ * the default distanceThresh = 50 and no mask).  pts are n x 2 double pixel
+ * coordinates.  mask (optional, n bytes) is in/out: rows with mask 0 do not
+ * vote; on return it marks the points in front of both cameras of the chosen
+ * pose.  votes (optional) receives the four candidates' counts in OpenCV's
+ * order (R1,t) (R2,t) (R1,-t) (R2,-t).  Returns the winning count, -1 on bad
+ * arguments or a rank-deficient E.
+ */
+int oracle_recover_pose(const double* E, const double* pts1, const double* pts2, int n,
+                        const double* K, double distance_thresh, double* R_out, double* t_out,
+                        uint8_t* mask, int32_t* votes);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
-"""Times the two drop-in calls with HOST buffers (upload, conversion, compute,
-download all inside): sfm_gpu_knn_match and sfm_gpu_ransac as the reference
-would call them (main.cpp:184, :224)."""
+"""Times the drop-in calls with HOST buffers (upload, conversion, compute,
+download all inside): sfm_gpu_knn_match, sfm_gpu_ransac and sfm_gpu_recover_pose
+as the reference would call them (main.cpp:184, :224, :420).  With ORACLE=1 the
+CPU oracle's recover_pose is timed beside the GPU call."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -29,6 +30,27 @@ def main():
         for _ in range(reps):
             E, mask, r = matcher.findEssentialMat(ctx, p1, p2, synth.REF_K, prob=0.99, threshold=1.0)
         t_rs = (time.perf_counter() - t0) / reps
+        for _ in range(2):
+            matcher.recoverPose(ctx, E, p1, p2, synth.REF_K)
+        t0 = time.perf_counter()
+        for _ in range(reps * 4):
+            ng, R, t, pm = matcher.recoverPose(ctx, E, p1, p2, synth.REF_K)
+        t_pose = (time.perf_counter() - t0) / (reps * 4)
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        matcher.recoverPose(ctx, E, p1, p2, synth.REF_K)
+        k_ms, _ = ctx.profile_query("pose_vote")
+        ctx.profile_enable(False)
+        extra = ""
+        if os.environ.get("ORACLE"):
+            from oracle import pyoracle as po
+            t0 = time.perf_counter()
+            for _ in range(reps * 4):
+                o = po.recover_pose(E, p1, p2, synth.REF_K)
+            extra = "; CPU oracle %.3f ms" % ((time.perf_counter() - t0) / (reps * 4) * 1e3)
+            assert o["n_good"] == ng and (o["mask"] == pm).all()
+        print("n=%d: recoverPose(%d pts) %.3f ms host call, vote kernel %.1f us, %d in front%s" %
+              (n, len(p1), t_pose * 1e3, k_ms * 1e3, ng, extra))
         mb = 2 * n * 128 * 4 / 1e6
         print("n=%d: knnMatch(host f32, %.0f MB up) %.2f ms; findEssentialMat(%d pts, adaptive) %.2f ms, "
               "%d iterations, %d inliers" % (n, mb, t_knn * 1e3, len(p1), t_rs * 1e3, r["iters"], r["n_inliers"]))

@@ -131,6 +131,9 @@ struct sfm_gpu_ctx {
     sfm::PinnedBuf pin_a, pin_b;  // host staging for results / counts / descriptors of jobs
     // match_pairs workspaces
     sfm::DevBuf mp_good, mp_pts, mp_ngood;
+    // recover_pose workspaces
+    sfm::DevBuf pose_in, pose_out;
+    int32_t dbg_pose_votes[4] = {0, 0, 0, 0};
 
     // device pointers of the last sfm_gpu_ransac call, for the test hooks
     const int32_t* dbg_table = nullptr;

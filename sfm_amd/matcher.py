@@ -176,6 +176,40 @@ def findFundamentalMat(ctx, points1, points2, method=FM_RANSAC, ransacReprojThre
     return r["F"], r["mask"], r
 
 
+def recoverPose(ctx, E, points1, points2, cameraMatrix, distanceThresh=50.0, mask=None):
+    """cv::recoverPose(E, points1, points2, cameraMatrix, R, t[, distanceThresh, mask])
+    as called at main.cpp:420 and bundle_adjustment.h:80.  Returns
+    (n_good, R, t, mask) like cv2.recoverPose: R 3x3, t 3x1 with |t| = 1, mask
+    n bytes (the mask passed in restricts which rows vote)."""
+    E = np.ascontiguousarray(E, dtype=np.float64).reshape(3, 3)
+    pts1 = np.ascontiguousarray(points1, dtype=np.float64).reshape(-1, 2)
+    pts2 = np.ascontiguousarray(points2, dtype=np.float64).reshape(-1, 2)
+    n = pts1.shape[0]
+    if pts2.shape[0] != n:
+        raise ValueError("point arrays differ in length")
+    Kc = np.ascontiguousarray(cameraMatrix, dtype=np.float64).reshape(3, 3)
+    if mask is None:
+        m = np.ones(n, dtype=np.uint8)
+    else:
+        m = np.array(mask, dtype=np.uint8).reshape(-1)
+        if m.shape[0] != n:
+            raise ValueError("mask and points differ in length")
+    R = np.zeros((3, 3), dtype=np.float64)
+    t = np.zeros((3, 1), dtype=np.float64)
+    good = ctypes.c_int32(0)
+    ctx.check(ctx._L.sfm_gpu_recover_pose(ctx.handle, ptr(E), ptr(pts1), ptr(pts2), n, ptr(Kc),
+                                          float(distanceThresh), ptr(R), ptr(t), ptr(m),
+                                          ctypes.byref(good)))
+    return good.value, R, t, m
+
+
+def pose_votes(ctx):
+    """Vote counts of the four candidates in the last recoverPose call."""
+    v = np.zeros(4, dtype=np.int32)
+    ctx.check(ctx._L.sfm_gpu_debug_pose_votes(ctx.handle, ptr(v)))
+    return v
+
+
 class Image:
     """One image's descriptors (+ keypoints) resident on the GPU
     (descriptors[i] / keypoints[i] of main.cpp:175-178)."""

@@ -54,10 +54,11 @@ def _rot(axis, ang):
     return np.eye(3) + np.sin(ang) * kx + (1 - np.cos(ang)) * (kx @ kx)
 
 
-def two_view(n, seed, inlier_frac=0.9, noise_px=0.5, K=REF_K):
+def two_view(n, seed, inlier_frac=0.9, noise_px=0.5, K=REF_K, with_pose=False):
     """n correspondences in pixels (float32 precision, stored float64 like the
     Point2f -> Point2d widening at main.cpp:194-195).  Returns
-    (pts1, pts2, is_inlier, E_true) with E_true for normalised coordinates."""
+    (pts1, pts2, is_inlier, E_true) with E_true for normalised coordinates;
+    with_pose adds (R, t_unit) of X2 = R X1 + t, the pose recoverPose reports."""
     rng = np.random.default_rng(seed)
     n_in = int(round(n * inlier_frac))
     Kinv = np.linalg.inv(K)
@@ -88,6 +89,8 @@ def two_view(n, seed, inlier_frac=0.9, noise_px=0.5, K=REF_K):
     tx = np.array([[0, -tn[2], tn[1]], [tn[2], 0, -tn[0]], [-tn[1], tn[0], 0]])
     E = tx @ R
     E /= np.linalg.norm(E)
+    if with_pose:
+        return pts1, pts2, is_in, E, R, tn
     return pts1, pts2, is_in, E
 
 

@@ -9,7 +9,7 @@ a diff against history and (b) the GPU path is checked against bytes that do
 not depend on the oracle being rebuilt.  Inputs are stored too, so the files
 are self-contained.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [knn] [essential] [fundamental] [pose]
 """
 import os
 import sys
@@ -52,10 +52,32 @@ def ransac_case(name, model, n, seed, hyps):
         adaptive_n_inliers=adaptive["n_inliers"], adaptive_iters=adaptive["iters"])
 
 
+def pose_case():
+    """The chain of main.cpp:418-420: essential matrix by RANSAC, then the pose."""
+    p1, p2, _, _ = synth.two_view(600, 23, 0.7, 0.4)
+    K = synth.REF_K
+    e = po.ransac(p1, p2, K, model=po.MODEL_ESSENTIAL, prob=0.999, threshold=1.0)
+    assert e["ok"] == 1
+    free = po.recover_pose(e["model"], p1, p2, K)
+    masked = po.recover_pose(e["model"], p1, p2, K, mask=e["mask"])
+    near = po.recover_pose(e["model"], p1, p2, K, distance_thresh=25.0)
+    np.savez_compressed(
+        os.path.join(HERE, "pose_essential.npz"), pts1=p1, pts2=p2, K=K, E=e["model"], ransac_mask=e["mask"],
+        R=free["R"], t=free["t"], mask=free["mask"], votes=free["votes"], n_good=free["n_good"],
+        masked_mask=masked["mask"], masked_votes=masked["votes"],
+        near_mask=near["mask"], near_votes=near["votes"])
+
+
 def main():
-    knn_case()
-    ransac_case("ransac_essential.npz", po.MODEL_ESSENTIAL, 400, 21, 96)
-    ransac_case("ransac_fundamental.npz", po.MODEL_FUNDAMENTAL, 500, 22, 128)
+    which = sys.argv[1:] or ["knn", "essential", "fundamental", "pose"]
+    if "knn" in which:
+        knn_case()
+    if "essential" in which:
+        ransac_case("ransac_essential.npz", po.MODEL_ESSENTIAL, 400, 21, 96)
+    if "fundamental" in which:
+        ransac_case("ransac_fundamental.npz", po.MODEL_FUNDAMENTAL, 500, 22, 128)
+    if "pose" in which:
+        pose_case()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -44,6 +44,19 @@ def test_oracle_reproduces_ransac_golden(oracle, name, model):
     assert (a["model"].view(np.uint64) == g["adaptive_model"].view(np.uint64)).all()
 
 
+def test_oracle_reproduces_pose_golden(oracle):
+    g = load("pose_essential.npz")
+    r = oracle.recover_pose(g["E"], g["pts1"], g["pts2"], g["K"])
+    assert (r["R"].view(np.uint64) == g["R"].view(np.uint64)).all()
+    assert (r["t"].view(np.uint64) == g["t"].view(np.uint64)).all()
+    assert (r["mask"] == g["mask"]).all() and (r["votes"] == g["votes"]).all()
+    assert r["n_good"] == int(g["n_good"])
+    m = oracle.recover_pose(g["E"], g["pts1"], g["pts2"], g["K"], mask=g["ransac_mask"])
+    assert (m["mask"] == g["masked_mask"]).all() and (m["votes"] == g["masked_votes"]).all()
+    n = oracle.recover_pose(g["E"], g["pts1"], g["pts2"], g["K"], distance_thresh=25.0)
+    assert (n["mask"] == g["near_mask"]).all() and (n["votes"] == g["near_votes"]).all()
+
+
 # ---- GPU: the HIP path against the same bytes -----------------------------
 
 @pytest.mark.gpu
@@ -81,3 +94,22 @@ def test_gpu_ransac_equals_golden(gpu_ctx, name, model):
     assert (np.asarray(r["model"]).view(np.uint64) == g["fixed_model"].view(np.uint64)).all()  # and in fact equal
     assert ar["iters"] == int(g["adaptive_iters"]) and (amask == g["adaptive_mask"]).all()
     assert (np.asarray(ar["model"]).view(np.uint64) == g["adaptive_model"].view(np.uint64)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_pose_equals_golden(gpu_ctx):
+    from sfm_amd import matcher
+    g = load("pose_essential.npz")
+    good, R, t, mask = matcher.recoverPose(gpu_ctx, g["E"], g["pts1"], g["pts2"], g["K"])
+    np.testing.assert_allclose(R, g["R"], rtol=0, atol=1e-6)  # stated tolerance
+    assert (R.view(np.uint64) == g["R"].view(np.uint64)).all()  # and in fact equal
+    assert (t.reshape(3).view(np.uint64) == g["t"].view(np.uint64)).all()
+    assert good == int(g["n_good"]) and (mask == g["mask"]).all()
+    assert (matcher.pose_votes(gpu_ctx) == g["votes"]).all()
+    _, _, _, mm = matcher.recoverPose(gpu_ctx, g["E"], g["pts1"], g["pts2"], g["K"], mask=g["ransac_mask"])
+    assert (mm == g["masked_mask"]).all() and (matcher.pose_votes(gpu_ctx) == g["masked_votes"]).all()
+    _, _, _, nm = matcher.recoverPose(gpu_ctx, g["E"], g["pts1"], g["pts2"], g["K"], distanceThresh=25.0)
+    assert (nm == g["near_mask"]).all() and (matcher.pose_votes(gpu_ctx) == g["near_votes"]).all()
+    # the chain of main.cpp:418-420 on the GPU gives the same E, hence the same pose
+    E, _, r = matcher.findEssentialMat(gpu_ctx, g["pts1"], g["pts2"], g["K"], prob=0.999, threshold=1.0)
+    assert (np.asarray(E).view(np.uint64) == g["E"].view(np.uint64)).all()

@@ -236,3 +236,75 @@ def test_ransac_fixed_count_is_replayable(oracle):
                        want_counts=True)
     assert (ra["counts"][:ra["iters"]] == rf["counts"][:ra["iters"]]).all()
     assert (ra["mask"] == rf["mask"]).all()
+
+
+# ---- pose recovery (main.cpp:420) -----------------------------------------
+
+def test_svd3_factorises(oracle):
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        A = rng.normal(size=(3, 3))
+        ok, U, S, V = oracle.svd3(A)
+        assert ok == 1
+        assert np.abs(U @ np.diag(S) @ V.T - A).max() < 1e-13
+        assert np.abs(np.abs(S) - np.linalg.svd(A)[1]).max() < 1e-13
+        assert abs(np.linalg.det(U) - 1) < 1e-13 and np.abs(V.T @ V - np.eye(3)).max() < 1e-13
+    assert oracle.svd3(np.zeros((3, 3)))[0] == 0
+    assert oracle.svd3(np.outer([1.0, 2, 3], [4.0, 5, 6]))[0] == 0  # rank 1
+
+
+def test_decompose_essential_candidates(oracle):
+    from sfm_amd import synth
+    for seed in range(10):
+        _, _, _, E, R, t = synth.two_view(50, seed, with_pose=True)
+        ok, R1, R2, tt = oracle.decompose_essential(E)
+        assert ok == 1
+        for Rc in (R1, R2):
+            assert np.abs(Rc @ Rc.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(Rc) - 1) < 1e-12
+            tx = np.array([[0, -tt[2], tt[1]], [tt[2], 0, -tt[0]], [-tt[1], tt[0], 0]])
+            Ec = tx @ Rc
+            Ec /= np.linalg.norm(Ec)
+            assert min(np.abs(Ec - E).max(), np.abs(Ec + E).max()) < 1e-12
+        assert abs(np.linalg.norm(tt) - 1) < 1e-12
+        assert min(np.abs(R1 - R).max(), np.abs(R2 - R).max()) < 1e-9
+        assert min(np.abs(tt - t).max(), np.abs(tt + t).max()) < 1e-9
+
+
+def test_recover_pose_finds_the_planted_pose(oracle):
+    from sfm_amd import synth
+    for seed in range(12):
+        p1, p2, is_in, E, R, t = synth.two_view(700, seed, inlier_frac=0.8, with_pose=True)
+        r = oracle.recover_pose(E, p1, p2, synth.REF_K)
+        assert np.abs(r["R"] - R).max() < 1e-9 and np.abs(r["t"] - t).max() < 1e-9
+        assert r["n_good"] == r["votes"].max() == int(r["mask"].sum())
+        assert r["mask"][is_in].mean() > 0.99
+        # E is defined up to sign; the pose is not
+        r2 = oracle.recover_pose(-E, p1, p2, synth.REF_K)
+        assert np.abs(r2["R"] - R).max() < 1e-9 and np.abs(r2["t"] - t).max() < 1e-9
+        assert (r2["mask"] == r["mask"]).all()
+        # swapping the images gives the inverse pose
+        r3 = oracle.recover_pose(E.T, p2, p1, synth.REF_K)
+        assert np.abs(r3["R"] - R.T).max() < 1e-9
+        tb = -R.T @ t
+        assert np.abs(r3["t"] - tb / np.linalg.norm(tb)).max() < 1e-9
+
+
+def test_recover_pose_mask_and_distance(oracle):
+    from sfm_amd import synth
+    p1, p2, is_in, E, R, t = synth.two_view(500, 3, inlier_frac=0.75, with_pose=True)
+    K = synth.REF_K
+    full = oracle.recover_pose(E, p1, p2, K)
+    # rows masked out do not vote and stay 0
+    m = (np.arange(500) % 3 != 0).astype(np.uint8)
+    part = oracle.recover_pose(E, p1, p2, K, mask=m)
+    assert (part["mask"] == (full["mask"] & m)).all() and part["n_good"] == int((full["mask"] & m).sum())
+    # synthetic depths are 17..37.4 baselines: a threshold below them rejects everything planted
+    near = oracle.recover_pose(E, p1, p2, K, distance_thresh=10.0)
+    assert near["mask"][is_in].sum() == 0
+    mid = oracle.recover_pose(E, p1, p2, K, distance_thresh=27.0)
+    assert 0 < mid["mask"][is_in].sum() < full["mask"][is_in].sum()
+    # no points: OpenCV's tie order picks the first candidate
+    ok, R1, _, tt = oracle.decompose_essential(E)
+    none = oracle.recover_pose(E, np.zeros((0, 2)), np.zeros((0, 2)), K)
+    assert none["n_good"] == 0 and (none["R"] == R1).all() and (none["t"] == tt).all()
+    assert oracle.recover_pose(np.zeros((3, 3)), p1, p2, K)["n_good"] == -1
