@@ -48,6 +48,14 @@ int sfm_gpu_debug_sqrt_probe(sfm_gpu_ctx* ctx, int32_t* mismatches);
  * tests prove it.  Process-wide. */
 int sfm_gpu_debug_set_score_filter(int on);
 
+/* Fixed-count RANSAC scores its candidate models in stages over the points and,
+ * between stages, drops the models that provably cannot reach the best count
+ * (their entries in the dumped counts stay partial, never above the true
+ * count).  0 switches the pruning off so that every dumped count is complete;
+ * 1 (default) on.  The selected model, its inlier count and the mask are the
+ * same either way.  Process-wide. */
+int sfm_gpu_debug_set_score_prune(int on);
+
 /* Vote counts of the four pose candidates in the last sfm_gpu_recover_pose call
  * on this context, in the order (R1,t) (R2,t) (R1,-t) (R2,-t). */
 int sfm_gpu_debug_pose_votes(sfm_gpu_ctx* ctx, int32_t* votes4);

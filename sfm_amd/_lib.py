@@ -96,6 +96,7 @@ def lib():
     L.sfm_gpu_debug_ransac_dump.argtypes = [vp, c.c_int, vp, vp, vp, vp]
     L.sfm_gpu_debug_set_score_filter.argtypes = [c.c_int]
     L.sfm_gpu_debug_pose_votes.argtypes = [vp, vp]
+    L.sfm_gpu_debug_set_score_prune.argtypes = [c.c_int]
     L.sfm_gpu_recover_pose.argtypes = [vp, vp, vp, vp, c.c_int, vp, c.c_double, vp, vp, vp, vp]
     _lib = L
     return L

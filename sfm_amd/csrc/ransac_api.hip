@@ -153,8 +153,11 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, rp.model, 0, nh));
         }
         {
+            // first stage of the scoring: 1/8 of the points when `cap` is the
+            // point count itself (direct call), 1/16 when it is the query count of
+            // a pair, of which the ratio test leaves less than half
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh));
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh, need_results ? 8 : 16));
         }
         {
             ProfScope ps(ctx, "ransac_select");
@@ -204,7 +207,7 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         }
         {
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, done_rows, b));
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, done_rows, b, 0));
         }
         counts.resize((size_t)n_prob * b * 10);
         // the problems' workspaces are carved at a constant stride: one strided copy
@@ -296,6 +299,12 @@ extern "C" {
 int sfm_gpu_debug_set_score_filter(int on)
 {
     sfm::set_ransac_score_filter(on);
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_debug_set_score_prune(int on)
+{
+    sfm::set_ransac_score_prune(on);
     return SFM_GPU_OK;
 }
 

@@ -20,6 +20,7 @@ enum {
     R_N = 9,       // copy of the point count
     R_NLIST = 10,  // candidate models listed for the batch being scored
     R_MAXABS = 11, // largest |coordinate| of the problem's points, float32 bits
+    R_BOUND = 12,  // largest complete inlier count known so far in the batch being scored
     R_COUNT = 16
 };
 
@@ -54,9 +55,14 @@ hipError_t launch_ransac_prep(hipStream_t s, const RansacProb* probs, int n_prob
 hipError_t launch_ransac_table(hipStream_t s, const RansacProb* probs, int n_prob, int row0, int nrows);
 hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int n_prob, int nrows);
 hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp);
+// prune > 0: every model is first scored on 1/prune of the point capacity,
+// then the models that provably cannot reach the best count are dropped (their
+// counts stay partial) and the rest go on; the selected model, its count and
+// the mask are the same as with prune = 0.
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
-                               int n_hyp);
+                               int n_hyp, int prune);
 void set_ransac_score_filter(int on);
+void set_ransac_score_prune(int on);
 hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp);
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
 

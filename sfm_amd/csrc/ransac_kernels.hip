@@ -14,6 +14,7 @@
 // order is untouched), and this file is compiled with -ffp-contract=off so no
 // multiply-add is fused.
 #include <cfloat>
+#include <climits>
 
 #include "sfm_ctx.h"
 #include "ransac_dev.h"
@@ -1343,7 +1344,10 @@ __global__ void __launch_bounds__(1024) ransac_compact_kernel(const RansacProb* 
         if (tid == 1023) s_running = base + incl;
         __syncthreads();
     }
-    if (tid == 0) pb.result[R_NLIST] = s_running;
+    if (tid == 0) {
+        pb.result[R_NLIST] = s_running;
+        pb.result[R_BOUND] = 0;
+    }
 }
 
 // den > 0 && den <= DBL_MAX in one instruction: positive normal or denormal
@@ -1537,22 +1541,28 @@ __device__ __forceinline__ f2v filter_h_out(const PairTerms& t, const FilterCons
 // registers; the points of the chunk are the same for every lane and are read
 // through scalar loads (nothing writes them while this kernel runs), so a
 // point costs each model nothing but its own arithmetic.
-// grid = (groups of 64 models, point chunks, problems).
+// grid = (groups of 64 models, point chunks from chunk0 on, problems); a
+// workgroup strides over further groups / chunks when the grid is smaller than
+// the work, keeping its models in registers from chunk to chunk.
+constexpr int SCORE_WAVES = 1;  // independent wavefronts per workgroup
 template <int MODEL>
-__global__ void __launch_bounds__(64) ransac_score_kernel(const RansacProb* __restrict__ probs, int chunk_pts,
-                                                          int use_filter)
+__global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const RansacProb* __restrict__ probs, int chunk_pts,
+                                                          int use_filter, int chunk0, int pts_end)
 {
     typedef const double __attribute__((address_space(4))) cdouble;
     typedef const f2v __attribute__((address_space(4))) cf2v;
     const RansacProb pb = probs[blockIdx.z];
     const int nlist = __builtin_amdgcn_readfirstlane(pb.result[R_NLIST]);
-    const int g0 = blockIdx.x * 64;
-    if (g0 >= nlist) return;
-    const int n = __builtin_amdgcn_readfirstlane(*pb.n_ptr);
-    const int i0 = blockIdx.y * chunk_pts;  // chunk_pts is even
-    const int i1 = min(n, i0 + chunk_pts);
-    if (i0 >= i1) return;
-    const int lane = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (((int)blockIdx.x * SCORE_WAVES + wv) * 64 >= nlist) return;
+    // this launch covers the points [chunk0 * chunk_pts, min(n, pts_end))
+    const int n = min(__builtin_amdgcn_readfirstlane(*pb.n_ptr), pts_end);
+    if ((chunk0 + (int)blockIdx.y) * chunk_pts >= n) return;  // chunk_pts is a multiple of 4
+    const int lane = threadIdx.x & 63;
+    constexpr int QCAP = 16;
+    __shared__ unsigned short parked_all[SCORE_WAVES * QCAP * 64];
+    unsigned short* parked = parked_all + wv * (QCAP * 64);
+    for (int g0 = (blockIdx.x * SCORE_WAVES + wv) * 64; g0 < nlist; g0 += gridDim.x * SCORE_WAVES * 64) {
     const bool active = g0 + lane < nlist;
     const int e = pb.list[active ? g0 + lane : g0];
     const double* Mg = pb.models + (size_t)(e / MAX_MODELS) * 90 + (e % MAX_MODELS) * 9;
@@ -1569,23 +1579,23 @@ __global__ void __launch_bounds__(64) ransac_score_kernel(const RansacProb* __re
         return symepi_inlier_u(M, X1[2 * i], X1[2 * i + 1], X2[2 * i], X2[2 * i + 1], tf, tlo, thi);
     };
     int cnt = 0;
+    const float R = __int_as_float(__builtin_amdgcn_readfirstlane(pb.result[R_MAXABS]));
+    const FilterConst fc = make_filter<MODEL>(M, (double)R, tf);
+    float Mf[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Mf[k] = (float)M[k];
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* S = (cfloat*)(uintptr_t)pb.soa;
+    for (int i0 = (chunk0 + blockIdx.y) * chunk_pts; i0 < n; i0 += gridDim.y * chunk_pts) {
+    const int i1 = min(n, i0 + chunk_pts);
     int i = i0;
     // Tests the filter cannot settle are parked per lane (offset within the
     // chunk) and redone in double precision after the sweep, so that one
     // lane's doubt does not make the other 63 wait at every such point.
-    constexpr int QCAP = 40;
-    __shared__ unsigned short parked[QCAP * 64];
     int n_parked = 0;
     if (use_filter) {
-        const float R = __int_as_float(__builtin_amdgcn_readfirstlane(pb.result[R_MAXABS]));
-        const FilterConst fc = make_filter<MODEL>(M, (double)R, tf);
-        float Mf[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Mf[k] = (float)M[k];
-        typedef const float __attribute__((address_space(4))) cfloat;
-        cfloat* S = (cfloat*)(uintptr_t)pb.soa;
         auto park = [&](int idx) {
-            if (use_filter == 2) return;  // timing experiment: unsettled tests are dropped (wrong counts)
+            if (use_filter >= 2) return;  // timing experiments: unsettled tests are dropped (wrong counts)
             if (n_parked < QCAP) {
                 parked[n_parked * 64 + lane] = (unsigned short)(idx - i0);
                 ++n_parked;
@@ -1607,7 +1617,11 @@ __global__ void __launch_bounds__(64) ransac_score_kernel(const RansacProb* __re
             f2v cur[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) cur[k] = nx[k];
-            fetch(i + 4 < i4 ? i + 4 : i);  // the last step re-reads its own points
+            // the loads of the next block go out before this block's arithmetic
+            // starts, so that they have the whole step to arrive
+            __builtin_amdgcn_sched_barrier(0);
+            if (use_filter != 3) fetch(i + 4 < i4 ? i + 4 : i);  // the last step re-reads its own points
+            __builtin_amdgcn_sched_barrier(0);
             const PairTerms tA = filter_terms<MODEL>(Mf, cur[0], cur[2], cur[4], cur[6]);
             const PairTerms tB = filter_terms<MODEL>(Mf, cur[1], cur[3], cur[5], cur[7]);
             const f2v hinA = filter_h_in(tA, fc), hinB = filter_h_in(tB, fc);
@@ -1629,7 +1643,104 @@ __global__ void __launch_bounds__(64) ransac_score_kernel(const RansacProb* __re
     }
     for (; i < i1; ++i) cnt += exact(i);
     for (int k = 0; k < n_parked; ++k) cnt += exact(i0 + (int)parked[k * 64 + lane]);
+    }  // chunks
     if (active && cnt != 0) atomicAdd(&pb.counts[e], cnt);
+    }  // groups
+}
+
+// Between two scoring stages of a fixed-count batch (points [0, pts_done) are
+// counted for every listed model): the listed model with the largest partial
+// count is completed here over the remaining points, which gives a lower bound
+// B on the count the winner will have; a model whose partial count plus all the
+// remaining points stays below B can neither win nor tie, so it leaves the
+// list.  Survivors keep their scan order.  One workgroup per problem.
+__global__ void __launch_bounds__(1024) ransac_prune_kernel(const RansacProb* __restrict__ probs, int pts_done)
+{
+    __shared__ unsigned long long sh[16];
+    __shared__ int wsum[16];
+    __shared__ int s_running, s_bound, s_pos;
+    const RansacProb pb = probs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = *pb.n_ptr;
+    const int nlist = pb.result[R_NLIST];
+    if (pts_done >= n || nlist <= 0) return;
+    // the listed model with the largest partial count
+    unsigned long long best = 0;
+    for (int p = tid; p < nlist; p += 1024) {
+        const unsigned c = (unsigned)pb.counts[pb.list[p]];
+        const unsigned long long key = ((unsigned long long)c << 32) | (0xFFFFFFFFu - (unsigned)p);
+        best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) sh[wv] = best;
+    __syncthreads();
+    best = sh[0];
+    for (int w = 1; w < 16; ++w) best = sh[w] > best ? sh[w] : best;
+    const int pos = (int)(0xFFFFFFFFu - (unsigned)best);
+    const int e = pb.list[pos];
+    // its count over the remaining points, by the procedure of the mask
+    {
+        const double* Mg = pb.models + (size_t)(e / MAX_MODELS) * 90 + (e % MAX_MODELS) * 9;
+        double M[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) M[i] = Mg[i];
+        int add = 0;
+        for (int i = pts_done + tid; i < n; i += 1024) {
+            if (pb.model == SFM_GPU_MODEL_ESSENTIAL)
+                add += sampson_inlier(M, pb.x1[2 * i], pb.x1[2 * i + 1], pb.x2[2 * i], pb.x2[2 * i + 1], pb.tf,
+                                      pb.tlo, pb.thi);
+            else
+                add += symepi_inlier(M, pb.f1[2 * i], pb.f1[2 * i + 1], pb.f2[2 * i], pb.f2[2 * i + 1], pb.tf,
+                                     pb.tlo, pb.thi);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) add += __shfl_xor(add, off);
+        if (lane == 0) wsum[wv] = add;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            const int full = (int)(best >> 32) + tot;
+            pb.counts[e] = full;
+            const int b = max(pb.result[R_BOUND], full);
+            pb.result[R_BOUND] = b;
+            s_bound = b;
+            s_pos = pos;
+            s_running = 0;
+        }
+        __syncthreads();
+    }
+    const int bound = s_bound, done_pos = s_pos, rest = n - pts_done;
+    // order-preserving compaction in place: a tile is read before anything is
+    // written, and writes never reach beyond the tile just read
+    for (int p0 = 0; p0 < nlist; p0 += 1024) {
+        const int p = p0 + tid;
+        int ent = -1;
+        if (p < nlist && p != done_pos) {
+            const int le = pb.list[p];
+            if (pb.counts[le] + rest >= bound) ent = le;
+        }
+        const int keep = ent >= 0 ? 1 : 0;
+        int incl = keep;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int base = s_running;
+        for (int w = 0; w < wv; ++w) base += wsum[w];
+        if (keep) pb.list[base + incl - 1] = ent;
+        __syncthreads();
+        if (tid == 1023) s_running = base + incl;
+        __syncthreads();
+    }
+    if (tid == 0) pb.result[R_NLIST] = s_running;
 }
 
 // Fixed-count winner: the first (hypothesis, model) in scan order whose count is
@@ -1710,6 +1821,9 @@ __global__ void __launch_bounds__(256) ransac_mask_kernel(const RansacProb* __re
 // test hook: 0 scores every point in double precision only
 int g_score_filter = 1;
 void set_ransac_score_filter(int on) { g_score_filter = on; }
+// test hook: 0 scores every listed model on every point even where pruning is allowed
+int g_score_prune = 1;
+void set_ransac_score_prune(int on) { g_score_prune = on; }
 
 hipError_t launch_ransac_prep(hipStream_t s, const RansacProb* probs, int n_prob, int cap)
 {
@@ -1736,19 +1850,40 @@ hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_pro
     return hipGetLastError();
 }
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
-                               int n_hyp)
+                               int n_hyp, int prune)
 {
     const int maxm = model == SFM_GPU_MODEL_ESSENTIAL ? 10 : 3;
     hipLaunchKernelGGL(ransac_compact_kernel, dim3(n_prob), dim3(1024), 0, s, probs, hyp0, n_hyp, maxm);
     const int chunk = 512;
-    const dim3 grid(((size_t)n_hyp * maxm + 63) / 64, (cap + chunk - 1) / chunk > 0 ? (cap + chunk - 1) / chunk : 1,
-                    n_prob);
-    if (model == SFM_GPU_MODEL_ESSENTIAL)
-        hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL>, grid, dim3(64), 0, s, probs, chunk,
-                           g_score_filter);
-    else
-        hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL>, grid, dim3(64), 0, s, probs, chunk,
-                           g_score_filter);
+    const int n_chunks = (cap + chunk - 1) / chunk > 0 ? (cap + chunk - 1) / chunk : 1;
+    const unsigned groups = (unsigned)(((size_t)n_hyp * maxm + 63) / 64);
+    auto score = [&](int chunk_pts, int chunk0, int chunks, unsigned gx, int pts_end) {
+        const dim3 grid((gx + SCORE_WAVES - 1) / SCORE_WAVES, chunks, n_prob);
+        if (model == SFM_GPU_MODEL_ESSENTIAL)
+            hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL>, grid, dim3(SCORE_WAVES * 64), 0, s, probs,
+                               chunk_pts,
+                               g_score_filter, chunk0, pts_end);
+        else
+            hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL>, grid, dim3(SCORE_WAVES * 64), 0, s, probs,
+                               chunk_pts,
+                               g_score_filter, chunk0, pts_end);
+    };
+    // Two stages with a pruning step between them: every model on the first
+    // 1/prune of the capacity (in half chunks: a single round of workgroups
+    // balances better when they are short), the survivors on the rest.  The
+    // bound only bites when the sample is larger than the outlier share of the
+    // points, the normal case behind a ratio test.
+    const int s1 = prune > 0 && n_chunks / prune > 1 ? n_chunks / prune : 1;
+    if (prune && g_score_prune && n_chunks > s1) {
+        score(chunk / 2, 0, 2 * s1, groups, s1 * chunk);
+        hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, s1 * chunk);
+        // the survivors are few: short chunks, and a grid a quarter of the list
+        // wide and at most 16 chunks deep that strides over whatever is left
+        const int rest = (n_chunks - s1) * 4;
+        score(chunk / 4, s1 * 4, rest < 16 ? rest : 16, (groups + 3) / 4, INT_MAX);
+    } else {
+        score(chunk, 0, n_chunks, groups, INT_MAX);
+    }
     return hipGetLastError();
 }
 hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp)

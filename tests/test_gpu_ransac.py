@@ -25,12 +25,21 @@ def _dump(ctx, n_hyp, m):
     return table, nmodels, counts, models
 
 
+@pytest.fixture
+def full_counts(gpu_ctx):
+    """Fixed-count scoring normally drops models that cannot win between its
+    stages; tests that compare every hypothesis' count switch that off."""
+    gpu_ctx._L.sfm_gpu_debug_set_score_prune(0)
+    yield
+    gpu_ctx._L.sfm_gpu_debug_set_score_prune(1)
+
+
 def _model_close(a, b, tol=1e-6):
     return np.abs(a - b).max() <= tol * np.abs(b).max()
 
 
 @pytest.mark.parametrize("seed,n,frac", [(7, 3000, 0.9), (8, 600, 0.6), (9, 14000, 0.8)])
-def test_essential_fixed_counts_mask_model(gpu_ctx, oracle, seed, n, frac):
+def test_essential_fixed_counts_mask_model(gpu_ctx, oracle, full_counts, seed, n, frac):
     p1, p2, is_in, _ = synth.two_view(n, seed, inlier_frac=frac)
     nh = 256
     E, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, prob=0.99, threshold=1.0,
@@ -105,7 +114,7 @@ def test_essential_degenerate_sizes(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("seed,n", [(21, 3300), (22, 900)])
-def test_fundamental_fixed_and_adaptive(gpu_ctx, oracle, seed, n):
+def test_fundamental_fixed_and_adaptive(gpu_ctx, oracle, full_counts, seed, n):
     p1, p2, _, _ = synth.two_view(n, seed, inlier_frac=0.8)
     nh = 512
     F, mask, r = matcher.findFundamentalMat(gpu_ctx, p1, p2, ransacReprojThreshold=3.0,
@@ -168,7 +177,7 @@ def _near_threshold_problem(model, seed, n_clean, n_edge, thr_px):
 
 
 @pytest.mark.parametrize("model,coord_scale", [(0, 1.0), (1, 1.0), (1, 64.0), (1, 1.0 / 64.0)])
-def test_scoring_filter_is_exact_on_near_threshold_points(gpu_ctx, oracle, model, coord_scale):
+def test_scoring_filter_is_exact_on_near_threshold_points(gpu_ctx, oracle, full_counts, model, coord_scale):
     thr = 1.0 if model == 0 else 3.0
     p1, p2, table = _near_threshold_problem(model, 77 + model, 1500, 4500, thr)
     if coord_scale != 1.0:
@@ -202,3 +211,38 @@ def test_scoring_filter_is_exact_on_near_threshold_points(gpu_ctx, oracle, model
     # all in nor all out, so many tests sat near the threshold
     best = o["counts"].max()
     assert 1500 + 200 < best < 6000 - 200
+
+
+@pytest.mark.parametrize("model", [0, 1])
+@pytest.mark.parametrize("seed,n,frac", [(31, 400, 0.9), (32, 513, 0.5), (33, 3300, 0.93), (34, 3300, 0.35),
+                                         (35, 14000, 0.8), (36, 5000, 0.05)])
+def test_pruned_scoring_selects_the_same_model(gpu_ctx, oracle, model, seed, n, frac):
+    """Default fixed-count scoring (staged, with models that cannot win dropped
+    between stages) against the oracle's exhaustive loop: same winner, count and
+    mask; the dumped counts are complete for every model that reaches the best
+    count and never exceed the true count elsewhere."""
+    p1, p2, _, _ = synth.two_view(n, seed, inlier_frac=frac)
+    nh = 256
+    m = 5 if model == 0 else 7
+    thr = 1.0 if model == 0 else 3.0
+    K = synth.REF_K if model == 0 else None
+    o = oracle.ransac(p1, p2, K, model=model, prob=0.99, threshold=thr, fixed_count=nh, want_counts=True)
+    if model == 0:
+        M, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, K, prob=0.99, threshold=thr,
+                                              mode=matcher.RANSAC_FIXED, n_hyp=nh)
+    else:
+        M, mask, r = matcher.findFundamentalMat(gpu_ctx, p1, p2, ransacReprojThreshold=thr, confidence=0.99,
+                                                mode=matcher.RANSAC_FIXED, n_hyp=nh)
+    _, _, counts, _ = _dump(gpu_ctx, nh, m)
+    assert r["ok"] == o["ok"] and r["n_inliers"] == o["n_inliers"]
+    assert (mask == o["mask"]).all()
+    if o["ok"]:
+        assert (np.asarray(M) == o["model"]).all()
+    oc = o["counts"]
+    assert (counts <= oc).all() and ((counts == -1) == (oc == -1)).all()
+    top = oc == oc.max()
+    assert (counts[top] == oc[top]).all()
+    if n >= 3000 and frac >= 0.9:
+        # the first stage (1/8 of the points) outnumbers the outliers, so the
+        # bound bites: most models were left with partial counts
+        assert (counts < oc)[oc >= 0].mean() > 0.3
