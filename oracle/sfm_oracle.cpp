@@ -244,6 +244,27 @@ void tighten_open_interval(const double* P, int k, bool open_lo, bool open_hi, d
     }
 }
 
+// Real roots, ascending, of q[0] + q[1] x + q[2] x^2 with q[2] != 0, by the
+// cancellation-free form of the quadratic formula (unfused arithmetic,
+// correctly rounded square root): none for a negative discriminant, the double
+// root once for a zero discriminant.
+int quadratic_roots(const double* q, double* r)
+{
+    const double a = q[2], b = q[1], c = q[0];
+    const double disc = b * b - 4.0 * a * c;
+    if (!(disc >= 0.0)) return 0;
+    if (disc == 0.0) {
+        r[0] = -b / (2.0 * a);
+        return 1;
+    }
+    const double s = std::sqrt(disc);
+    const double t = -0.5 * (b + (b < 0.0 ? -s : s));
+    const double r1 = t / a, r2 = c / t;
+    r[0] = r1 < r2 ? r1 : r2;
+    r[1] = r1 < r2 ? r2 : r1;
+    return 2;
+}
+
 // All real roots of c[0] + c[1] z + ... + c[n] z^n (n <= 10), ascending.
 // Level k of the recursion isolates the roots of the (n-k)-th derivative
 // between consecutive roots of the next derivative, where it is monotone.
@@ -251,6 +272,7 @@ int real_roots(const double* cin, int n, double* roots)
 {
     double c[11];
     double cmax = 0.0;
+    const bool small_degree = n <= 3;  // as given, before vanishing leading coefficients are dropped
     for (int i = 0; i <= n; i++) cmax = std::max(cmax, std::fabs(cin[i]));
     if (!(cmax > 0.0) || !std::isfinite(cmax)) return 0;
     for (int i = 0; i <= n; i++) c[i] = cin[i] / cmax;
@@ -268,7 +290,15 @@ int real_roots(const double* cin, int n, double* roots)
     int mprev = 1, mcur = 0;
     prev[0] = -D[1][0] / D[1][1];
     if (n == 1) { roots[0] = prev[0]; return 1; }
-    for (int k = 2; k <= n; k++) {
+    int k0 = 2;
+    if (small_degree) {
+        // Quadratics and cubics (the seven-point solver's polynomial): the
+        // quadratic level has a closed form; the cubic level then brackets
+        // between those critical points as every higher level does.
+        mprev = quadratic_roots(D[2], prev);
+        k0 = 3;
+    }
+    for (int k = k0; k <= n; k++) {
         // interval t = [e_t, e_{t+1}] with e_0 = -B, e_1..e_m the critical
         // points (clamped to [-B, B]), e_{m+1} = B; every interval is handled
         // independently of the others

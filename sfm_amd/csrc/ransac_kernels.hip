@@ -519,74 +519,6 @@ __device__ int five_point_wave(SolveWs& w, const double* x1s, const double* x2s,
     return __popcll(mask);
 }
 
-// Seven-point fundamental matrix solver on float32 pixel points, one
-// wavefront.  Up to 3 models, F33 = 1 when possible.
-__device__ int seven_point_wave(SolveWs& w, const float* m1, const float* m2, double* models, int lane)
-{
-    if (lane < 63) {
-        const int i = lane / 9, j = lane % 9;
-        const double x0 = m1[2 * i], y0 = m1[2 * i + 1], x1 = m2[2 * i], y1 = m2[2 * i + 1];
-        double q;
-        switch (j) {
-            case 0: q = x1 * x0; break;
-            case 1: q = x1 * y0; break;
-            case 2: q = x1; break;
-            case 3: q = y1 * x0; break;
-            case 4: q = y1 * y0; break;
-            case 5: q = y1; break;
-            case 6: q = x0; break;
-            case 7: q = y0; break;
-            default: q = 1.0; break;
-        }
-        w.Q[lane] = q;
-    }
-    __syncthreads();
-    if (!null_space_9(w, 7, lane)) return 0;
-    // f2 = N1, f1 = N0 - N1; entries of lambda*f1 + f2 as polynomials {f2, f1}
-    // stored in A[0][2i], A[0][2i+1]; f1, f2 kept in L[0], L[1]
-    if (lane < 9) {
-        const double f2 = w.N[9 + lane];
-        const double f1 = w.N[lane] - f2;
-        w.L[0][lane] = f1;
-        w.L[1][lane] = f2;
-        w.A[0][2 * lane] = f2;
-        w.A[0][2 * lane + 1] = f1;
-    }
-    __syncthreads();
-    const double* p = w.A[0];
-    if (lane < 9) {
-        const int which = lane / 3, i = lane % 3;
-        const int ia[3] = {4, 3, 3}, ib[3] = {8, 8, 7}, ic[3] = {5, 5, 4}, id[3] = {7, 6, 6};
-        w.M[which][i] = pmul_coef(p + 2 * ia[which], 1, p + 2 * ib[which], 1, i) -
-                        pmul_coef(p + 2 * ic[which], 1, p + 2 * id[which], 1, i);
-    }
-    __syncthreads();
-    if (lane < 4) {
-        const double t0 = pmul_coef(p + 0, 1, w.M[0], 2, lane);
-        const double t1 = pmul_coef(p + 2, 1, w.M[1], 2, lane);
-        const double t2 = pmul_coef(p + 4, 1, w.M[2], 2, lane);
-        w.c[lane] = (t0 - t1) + t2;
-    }
-    __syncthreads();
-    const int nr = real_roots(w, 3, lane);
-    if (lane < nr) {
-        const double* f1 = w.L[0];
-        const double* f2 = w.L[1];
-        double lambda = w.roots[lane], mu = 1.0;
-        const double s = f1[8] * lambda + f2[8];
-        double* F = models + 9 * lane;
-        if (fabs(s) > DBL_EPSILON) {
-            mu = 1.0 / s;
-            lambda = lambda * mu;
-            F[8] = 1.0;
-        } else {
-            F[8] = 0.0;
-        }
-        for (int i = 0; i < 8; ++i) F[i] = f1[i] * lambda + f2[i] * mu;
-    }
-    return nr;
-}
-
 
 // ---- seven-point solver, one THREAD per hypothesis -----------------------------
 // The seven-point algorithm is short and almost entirely sequential, so 64
@@ -691,8 +623,29 @@ __device__ __forceinline__ void root_interval(const double* P, const double* dP,
     }
 }
 
-// Real roots, ascending, of cin[0..3] (any coefficient may vanish): the
-// sequential statement of real_roots() above, degrees 3, 2 and 1 spelled out.
+// Real roots, ascending, of q[0] + q[1] x + q[2] x^2, q[2] != 0: cancellation-free
+// quadratic formula in unfused arithmetic with a correctly rounded square root;
+// the double root of a zero discriminant is reported once.
+__device__ __forceinline__ int quadratic_roots_t(const double* q, double* r)
+{
+    const double a = q[2], b = q[1], c = q[0];
+    const double disc = b * b - 4.0 * a * c;
+    if (!(disc >= 0.0)) return 0;
+    if (disc == 0.0) {
+        r[0] = -b / (2.0 * a);
+        return 1;
+    }
+    const double s = sqrt(disc);
+    const double t = -0.5 * (b + (b < 0.0 ? -s : s));
+    const double r1 = t / a, r2 = c / t;
+    r[0] = r1 < r2 ? r1 : r2;
+    r[1] = r1 < r2 ? r2 : r1;
+    return 2;
+}
+
+// Real roots, ascending, of cin[0..3] (any coefficient may vanish): polynomials
+// of degree <= 3 take the critical points of the cubic from the closed form and
+// bracket the cubic's own roots between them; degrees 3, 2 and 1 spelled out.
 __device__ __forceinline__ int real_roots3_thread(const double* cin, double* roots)
 {
     double cmax = 0.0;
@@ -705,21 +658,16 @@ __device__ __forceinline__ int real_roots3_thread(const double* cin, double* roo
     roots[0] = roots[1] = roots[2] = 0.0;
     if (c[3] != 0.0) {
         const double D2[3] = {1.0 * c[1], 2.0 * c[2], 3.0 * c[3]};
-        const double D1[2] = {1.0 * D2[1], 2.0 * D2[2]};
         double B = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) B = fmax(B, fabs(c[i] / c[3]));
         B = 1.0 + B;
         if (!(B < 1e25)) B = 1e25;
-        double prev[3] = {-D1[0] / D1[1], 0.0, 0.0};
+        double prev[3] = {0.0, 0.0, 0.0};
         double cur[3] = {0.0, 0.0, 0.0};
-        int mprev = 1, mcur = 0;
         // level 2: roots of the first derivative
-        root_interval<2>(D2, D1, -B, prev[0], B, false, true, false, cur, mcur);
-        root_interval<2>(D2, D1, prev[0], B, B, true, false, true, cur, mcur);
-        prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
-        mprev = mcur;
-        mcur = 0;
+        const int mprev = quadratic_roots_t(D2, prev);
+        int mcur = 0;
         // level 3: the polynomial itself, intervals t = 0..mprev
         root_interval<3>(c, D2, -B, mprev > 0 ? prev[0] : B, B, mprev == 0, mprev >= 1, false, cur, mcur);
         if (mprev >= 1)
@@ -728,21 +676,7 @@ __device__ __forceinline__ int real_roots3_thread(const double* cin, double* roo
         roots[0] = cur[0]; roots[1] = cur[1]; roots[2] = cur[2];
         return mcur;
     }
-    if (c[2] != 0.0) {
-        const double D1[2] = {1.0 * c[1], 2.0 * c[2]};
-        double B = 0.0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) B = fmax(B, fabs(c[i] / c[2]));
-        B = 1.0 + B;
-        if (!(B < 1e25)) B = 1e25;
-        const double e = -D1[0] / D1[1];
-        double cur[3] = {0.0, 0.0, 0.0};
-        int mcur = 0;
-        root_interval<2>(c, D1, -B, e, B, false, true, false, cur, mcur);
-        root_interval<2>(c, D1, e, B, B, true, false, true, cur, mcur);
-        roots[0] = cur[0]; roots[1] = cur[1];
-        return mcur;
-    }
+    if (c[2] != 0.0) return quadratic_roots_t(c, roots);
     if (c[1] != 0.0) {
         roots[0] = -c[0] / c[1];
         return 1;
@@ -1196,12 +1130,11 @@ __global__ void __launch_bounds__(64) ransac_table_kernel(const RansacProb* __re
     }
 }
 
-// One wavefront per hypothesis.
+// Five-point hypotheses, one wavefront each.
 __global__ void __launch_bounds__(64) ransac_solve_kernel(const RansacProb* __restrict__ probs, int hyp0)
 {
     __shared__ SolveWs ws;
     __shared__ double sx1[14], sx2[14];
-    __shared__ float sf1[14], sf2[14];
     const RansacProb pb = probs[blockIdx.y];
     const int hyp = hyp0 + blockIdx.x;
     const int lane = threadIdx.x;
@@ -1218,19 +1151,12 @@ __global__ void __launch_bounds__(64) ransac_solve_kernel(const RansacProb* __re
     }
     if (lane < 2 * m) {
         const int pt = row[lane >> 1], comp = lane & 1;
-        if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
-            sx1[lane] = pb.x1[2 * pt + comp];
-            sx2[lane] = pb.x2[2 * pt + comp];
-        } else {
-            sf1[lane] = pb.f1[2 * pt + comp];
-            sf2[lane] = pb.f2[2 * pt + comp];
-        }
+        sx1[lane] = pb.x1[2 * pt + comp];
+        sx2[lane] = pb.x2[2 * pt + comp];
     }
     __syncthreads();
     double* models = pb.models + (size_t)hyp * 90;
-    int nm;
-    if (pb.model == SFM_GPU_MODEL_ESSENTIAL) nm = five_point_wave(ws, sx1, sx2, models, lane);
-    else nm = seven_point_wave(ws, sf1, sf2, models, lane);
+    const int nm = five_point_wave(ws, sx1, sx2, models, lane);
     if (lane == 0) pb.nmodels[hyp] = nm;
 }
 
