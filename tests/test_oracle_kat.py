@@ -137,6 +137,28 @@ def test_real_roots_against_constructed_polynomials(oracle):
             assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
 
 
+def test_real_roots_small_degrees(oracle):
+    """Degrees <= 3 take the critical points from the quadratic formula.  (The
+    coefficients are scaled by their largest magnitude first, so even integer
+    roots come back only to a few units in the last place.)"""
+    def check(coef, want):
+        got = oracle.real_roots(coef)
+        assert len(got) == len(want), (coef, got)
+        for g, w in zip(got, want):
+            assert abs(g - w) <= 1e-14 * max(1.0, abs(w)), (coef, got)
+    check([2.0, -3.0, 1.0], [1.0, 2.0])            # (x-1)(x-2)
+    check([1.0, 0.0, 1.0], [])                      # x^2 + 1
+    check([1.0, -2.0, 1.0], [1.0])                  # (x-1)^2: the double root once
+    check([2.0, -3.0, 1.0, 0.0], [1.0, 2.0])        # vanishing leading term
+    check([-6.0, 11.0, -6.0, 1.0], [1.0, 2.0, 3.0])
+    check([0.0, 0.0, 0.0, 1.0], [0.0])              # x^3
+    check([1.0, 1.0, 1.0, 1.0], [-1.0])             # (x+1)(x^2+1)
+    check([-8.0, 4.0], [2.0])
+    # ill-scaled quadratic: the small root keeps full relative precision
+    r = oracle.real_roots([1.0, -1e8, 1.0])
+    assert abs(r[0] - 1e-8) < 1e-22 and abs(r[1] - 1e8) < 1e-6
+
+
 def test_update_num_iters(oracle):
     assert oracle.update_num_iters(0.99, 1 - 0.91, 5, 1000) == 5
     assert oracle.update_num_iters(0.99, 0.5, 5, 1000) == 145
