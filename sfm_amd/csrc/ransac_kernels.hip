@@ -643,19 +643,20 @@ __device__ __forceinline__ int quadratic_roots_t(const double* q, double* r)
     return 2;
 }
 
-// Real roots, ascending, of cin[0..3] (any coefficient may vanish): polynomials
-// of degree <= 3 take the critical points of the cubic from the closed form and
-// bracket the cubic's own roots between them; degrees 3, 2 and 1 spelled out.
-__device__ __forceinline__ int real_roots3_thread(const double* cin, double* roots)
+// Part k (0, 1, 2) of the real roots of cin[0..3] (any coefficient may vanish):
+// a cubic takes its critical points from the closed form and part k is the
+// interval between the (k-1)-th and the k-th of them, solved on its own; a
+// quadratic hands out its two closed-form roots, a linear polynomial its one.
+// The parts that report a root, taken in order of k, are the roots ascending.
+__device__ __forceinline__ bool real_root3_part(const double* cin, int k, double& r)
 {
     double cmax = 0.0;
 #pragma unroll
     for (int i = 0; i <= 3; ++i) cmax = fmax(cmax, fabs(cin[i]));
-    if (!(cmax > 0.0) || !(cmax <= DBL_MAX)) return 0;
+    if (!(cmax > 0.0) || !(cmax <= DBL_MAX)) return false;
     double c[4];
 #pragma unroll
     for (int i = 0; i <= 3; ++i) c[i] = cin[i] / cmax;
-    roots[0] = roots[1] = roots[2] = 0.0;
     if (c[3] != 0.0) {
         const double D2[3] = {1.0 * c[1], 2.0 * c[2], 3.0 * c[3]};
         double B = 0.0;
@@ -663,32 +664,37 @@ __device__ __forceinline__ int real_roots3_thread(const double* cin, double* roo
         for (int i = 0; i < 3; ++i) B = fmax(B, fabs(c[i] / c[3]));
         B = 1.0 + B;
         if (!(B < 1e25)) B = 1e25;
-        double prev[3] = {0.0, 0.0, 0.0};
+        double prev[2] = {0.0, 0.0};
+        const int mprev = quadratic_roots_t(D2, prev);  // level 2: roots of the first derivative
+        if (k > mprev) return false;
+        // level 3: interval k of the polynomial itself
+        const double lo = k == 0 ? -B : (k == 1 ? prev[0] : prev[1]);
+        const double hi = k < mprev ? (k == 0 ? prev[0] : prev[1]) : B;
         double cur[3] = {0.0, 0.0, 0.0};
-        // level 2: roots of the first derivative
-        const int mprev = quadratic_roots_t(D2, prev);
         int mcur = 0;
-        // level 3: the polynomial itself, intervals t = 0..mprev
-        root_interval<3>(c, D2, -B, mprev > 0 ? prev[0] : B, B, mprev == 0, mprev >= 1, false, cur, mcur);
-        if (mprev >= 1)
-            root_interval<3>(c, D2, prev[0], mprev > 1 ? prev[1] : B, B, mprev == 1, false, mprev == 1, cur, mcur);
-        if (mprev >= 2) root_interval<3>(c, D2, prev[1], B, B, true, false, true, cur, mcur);
-        roots[0] = cur[0]; roots[1] = cur[1]; roots[2] = cur[2];
-        return mcur;
+        root_interval<3>(c, D2, lo, hi, B, k == mprev, k == 0 && mprev >= 1, k == mprev && mprev >= 1, cur, mcur);
+        r = cur[0];
+        return mcur > 0;
     }
-    if (c[2] != 0.0) return quadratic_roots_t(c, roots);
+    if (c[2] != 0.0) {
+        double q[2] = {0.0, 0.0};
+        const int nq = quadratic_roots_t(c, q);
+        r = k == 0 ? q[0] : q[1];
+        return k < nq;
+    }
     if (c[1] != 0.0) {
-        roots[0] = -c[0] / c[1];
-        return 1;
+        r = -c[0] / c[1];
+        return k == 0;
     }
-    return 0;
+    return false;
 }
 
 #define SFM_SA(i, j) sA[((i) * 9 + (j)) * 64 + lane]
 
-// Seven-point fundamental matrix solver, one thread.  m1/m2: the 7 sampled
-// float32 pixel points.  Up to 3 models into F[3][9]; returns their number.
-__device__ int seven_point_thread(double* sA, int lane, const float* m1, const float* m2, double (*F)[9])
+// Seven-point fundamental matrix solver, one thread, first half.  m1/m2: the 7
+// sampled float32 pixel points.  Leaves the pencil f1, f2 (the models are
+// lambda f1 + f2 with det = 0); false when the system has rank < 7.
+__device__ bool seven_point_pencil(double* sA, int lane, const float* m1, const float* m2, double* f1, double* f2)
 {
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
@@ -748,7 +754,7 @@ __device__ int seven_point_thread(double* sA, int lane, const float* m1, const f
             SFM_SA(i, p) = 0.0;
         }
     }
-    if (!ok) return 0;
+    if (!ok) return false;
     // basis vectors N0, N1 scattered through the permutation into the (now
     // unused) first seven columns: N[k][c] at element (k*9 + c) -> slot (t/7, t%7)
     double nv[2][7];
@@ -768,18 +774,25 @@ __device__ int seven_point_thread(double* sA, int lane, const float* m1, const f
             sA[(((t / 7) * 9) + (t % 7)) * 64 + lane] = v;
         }
     }
-    double f1[9], f2[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         f2[i] = SFM_SN(9 + i);
         f1[i] = SFM_SN(i) - f2[i];
     }
 #undef SFM_SN
-    // det(lambda f1 + f2): entries are degree-1 polynomials p[i] = {f2[i], f1[i]}
+    return true;
+}
+#undef SFM_SA
+
+// Second half, spread over three threads per hypothesis: the cubic
+// det(lambda f1 + f2) into c[0..3] ...
+__device__ __forceinline__ void seven_point_cubic(const double* f1, const double* f2, double* c)
+{
+    // entries are degree-1 polynomials p[i] = {f2[i], f1[i]}
     double pp[9][2];
 #pragma unroll
     for (int i = 0; i < 9; ++i) { pp[i][0] = f2[i]; pp[i][1] = f1[i]; }
-    double a[3], b[3], m0[3], mm1[3], mm2[3], t0[4], t1[4], t2[4], c[4];
+    double a[3], b[3], m0[3], mm1[3], mm2[3], t0[4], t1[4], t2[4];
     pmul_t<1, 1>(pp[4], pp[8], a); pmul_t<1, 1>(pp[5], pp[7], b);
 #pragma unroll
     for (int i = 0; i < 3; ++i) m0[i] = a[i] - b[i];
@@ -794,26 +807,23 @@ __device__ int seven_point_thread(double* sA, int lane, const float* m1, const f
     pmul_t<1, 2>(pp[2], mm2, t2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) c[i] = (t0[i] - t1[i]) + t2[i];
-    double roots[3];
-    const int nr = real_roots3_thread(c, roots);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (k >= nr) break;
-        double lambda = roots[k], mu = 1.0;
-        const double s = f1[8] * lambda + f2[8];
-        if (fabs(s) > DBL_EPSILON) {
-            mu = 1.0 / s;
-            lambda = lambda * mu;
-            F[k][8] = 1.0;
-        } else {
-            F[k][8] = 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) F[k][i] = f1[i] * lambda + f2[i] * mu;
-    }
-    return nr;
 }
-#undef SFM_SA
+
+// ... and the model of one root lambda (F33 = 1 when possible).
+__device__ __forceinline__ void seven_point_model(const double* f1, const double* f2, double lambda, double* F)
+{
+    double mu = 1.0;
+    const double s = f1[8] * lambda + f2[8];
+    if (fabs(s) > DBL_EPSILON) {
+        mu = 1.0 / s;
+        lambda = lambda * mu;
+        F[8] = 1.0;
+    } else {
+        F[8] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) F[i] = f1[i] * lambda + f2[i] * mu;
+}
 
 // ---- error functions ---------------------------------------------------------
 
@@ -1160,7 +1170,11 @@ __global__ void __launch_bounds__(64) ransac_solve_kernel(const RansacProb* __re
     if (lane == 0) pb.nmodels[hyp] = nm;
 }
 
-// Seven-point hypotheses, one thread each (64 per workgroup).
+// Seven-point hypotheses, one thread each, in two kernels: the elimination
+// needs 32 KB of LDS per wavefront (five wavefronts per CU), the root finding
+// that follows needs none and runs at full occupancy.  The pencil travels
+// through the hypothesis' own slot of the models buffer; nmodels = -1 marks a
+// hypothesis whose pencil is waiting there.
 __global__ void __launch_bounds__(64) ransac_solve7_kernel(const RansacProb* __restrict__ probs, int hyp0, int n_hyp)
 {
     __shared__ double sA[63 * 64];
@@ -1198,21 +1212,57 @@ __global__ void __launch_bounds__(64) ransac_solve7_kernel(const RansacProb* __r
 #pragma unroll
         for (int k = 0; k < 14; ++k) m1[k] = m2[k] = 0.f;
     }
-    double F[3][9];
-    const int nm = seven_point_thread(sA, lane, m1, m2, F);
+    double f1[9], f2[9];
+    const bool ok = seven_point_pencil(sA, lane, m1, m2, f1, f2);
     if (!in_range) return;
-    if (!active) {
+    if (!active || !ok) {
         pb.nmodels[hyp] = 0;
         return;
     }
-    pb.nmodels[hyp] = nm;
+    pb.nmodels[hyp] = -1;
     double* dst = pb.models + (size_t)hyp * 90;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        if (k < nm) {
+    for (int i = 0; i < 9; ++i) {
+        dst[i] = f1[i];
+        dst[9 + i] = f2[i];
+    }
+}
+
+// Three lanes per hypothesis (21 hypotheses per wavefront, lane 63 idle), one
+// interval of the cubic each: the Newton loops of the three intervals run side
+// by side instead of one after the other, and three times as many wavefronts
+// hide the latency of their dependent double-precision chains.
+constexpr int ROOTS7_WAVES = 4;
+__global__ void __launch_bounds__(ROOTS7_WAVES * 64) ransac_roots7_kernel(const RansacProb* __restrict__ probs,
+                                                                        int hyp0, int n_hyp)
+{
+    const RansacProb pb = probs[blockIdx.y];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int k = lane % 3;
+    const int t = (blockIdx.x * ROOTS7_WAVES + wv) * 21 + lane / 3;
+    const int hyp = hyp0 + t;
+    // every lane of a hypothesis reads the flag and the pencil before any of them writes
+    const bool valid = lane < 63 && t < n_hyp && pb.nmodels[hyp] == -1;
+    double* dst = pb.models + (size_t)(valid ? hyp : hyp0) * 90;
+    double f1[9], f2[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) dst[9 * k + i] = F[k][i];
-        }
+    for (int i = 0; i < 9; ++i) {
+        f1[i] = valid ? dst[i] : 0.0;
+        f2[i] = valid ? dst[9 + i] : 0.0;
+    }
+    double c[4], r = 0.0;
+    seven_point_cubic(f1, f2, c);
+    const bool has = valid && real_root3_part(c, k, r);
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+    const unsigned mine = (unsigned)(mask >> (lane - k)) & 7u;  // the three parts of this hypothesis
+    if (has) {
+        double F[9];
+        seven_point_model(f1, f2, r, F);
+        const int pos = __popc(mine & ((1u << k) - 1u));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dst[9 * pos + i] = F[i];
+    }
+    if (valid && k == 0) pb.nmodels[hyp] = __popc(mine);
 }
 
 // Lists the candidate models of hypotheses [hyp0, hyp0+n_hyp) densely
@@ -1770,7 +1820,12 @@ hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int
 hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp)
 {
     if (model == SFM_GPU_MODEL_FUNDAMENTAL)
+    {
         hipLaunchKernelGGL(ransac_solve7_kernel, dim3((n_hyp + 63) / 64, n_prob), dim3(64), 0, s, probs, hyp0, n_hyp);
+        const int per_wg = ROOTS7_WAVES * 21;
+        hipLaunchKernelGGL(ransac_roots7_kernel, dim3((n_hyp + per_wg - 1) / per_wg, n_prob), dim3(ROOTS7_WAVES * 64),
+                           0, s, probs, hyp0, n_hyp);
+    }
     else
         hipLaunchKernelGGL(ransac_solve_kernel, dim3(n_hyp, n_prob), dim3(64), 0, s, probs, hyp0);
     return hipGetLastError();
@@ -1787,12 +1842,10 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
         const dim3 grid((gx + SCORE_WAVES - 1) / SCORE_WAVES, chunks, n_prob);
         if (model == SFM_GPU_MODEL_ESSENTIAL)
             hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL>, grid, dim3(SCORE_WAVES * 64), 0, s, probs,
-                               chunk_pts,
-                               g_score_filter, chunk0, pts_end);
+                               chunk_pts, g_score_filter, chunk0, pts_end);
         else
             hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL>, grid, dim3(SCORE_WAVES * 64), 0, s, probs,
-                               chunk_pts,
-                               g_score_filter, chunk0, pts_end);
+                               chunk_pts, g_score_filter, chunk0, pts_end);
     };
     // Two stages with a pruning step between them: every model on the first
     // 1/prune of the capacity (in half chunks: a single round of workgroups
