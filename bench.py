@@ -184,12 +184,14 @@ def main():
         ops_per_launch = 2.0 * n * n * 128 * B
         achieved = ops_per_launch / (knn["avg_us"] * 1e-6) / 1e12
         traffic = None
+        pipe_busy = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_knn2_mfma.json")
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
                 if pmc.get("pairs_per_launch") == B and pmc.get("n_desc") == n:
                     traffic = pmc.get("hbm_bytes_per_launch")
+                    pipe_busy = pmc.get("mfma_pipe_busy_frac")
             except Exception:
                 traffic = None
         out = {
@@ -222,6 +224,12 @@ def main():
                 "unit_note": "int8 multiply-add counted as 2 ops (TOP/s); peak = dense int8 MFMA",
                 "frac": round(achieved / INT8_DENSE_PEAK_TOPS, 4),
                 "traffic": traffic,
+                "mfma_pipe_busy": {
+                    "frac": pipe_busy,
+                    "what": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) from profiles/pmc_knn2_mfma.json: "
+                            "the share of the kernel's own clock cycles in which the matrix pipe is busy; frac above "
+                            "is against the nominal 2.4 GHz peak, the clock under this load is lower",
+                },
                 "ops_per_launch": ops_per_launch,
                 "avg_launch_us": knn["avg_us"],
                 "mfma_only_microkernel": {
