@@ -303,11 +303,18 @@ __device__ int real_roots(SolveWs& w, int n, int lane)
     return mprev;
 }
 
-// Five-point essential matrix solver (Nister 2004), one wavefront.
+// Layout of what the first half of the five-point solver leaves in a
+// hypothesis' slot of the models buffer (90 doubles) for the second half:
+// the degree-10 polynomial, the rows of B(z) and the null-space basis.
+constexpr int FP_C = 0;    // c[0..10]
+constexpr int FP_B = 11;   // 3 rows x (4 + 4 + 5) coefficients
+constexpr int FP_N = 50;   // N[4][9]
+
+// Five-point essential matrix solver (Nister 2004), first half, one wavefront.
 // x1s/x2s: the 5 normalised correspondences (uniform across the wave).
-// Writes up to 10 unit-Frobenius-norm models (row-major) to `models`, ascending
-// in the root z; returns their number (uniform).
-__device__ int five_point_wave(SolveWs& w, const double* x1s, const double* x2s, double* models, int lane)
+// Leaves polynomial, B(z) and null space in `slot`; false when the
+// elimination meets a zero pivot (no models).
+__device__ bool five_point_wave(SolveWs& w, const double* x1s, const double* x2s, double* slot, int lane)
 {
     if (lane < 45) {
         const int i = lane / 9, j = lane % 9;
@@ -327,7 +334,7 @@ __device__ int five_point_wave(SolveWs& w, const double* x1s, const double* x2s,
         w.Q[lane] = q;
     }
     __syncthreads();
-    if (!null_space_9(w, 5, lane)) return 0;
+    if (!null_space_9(w, 5, lane)) return false;
 
     // entry (r,c) of E = xX + yY + zZ + W as a degree-1 polynomial: gathered
     // per use from N (e[r][c][k] = N[k*9 + 3r + c]).
@@ -406,7 +413,7 @@ __device__ int five_point_wave(SolveWs& w, const double* x1s, const double* x2s,
             const double v = fabs(w.A[i][p]);
             if (v > best) { best = v; bi = i; }
         }
-        if (!(best > 0.0)) return 0;
+        if (!(best > 0.0)) return false;
         __syncthreads();
         if (bi != p && lane < 20) {
             const double t = w.A[p][lane];
@@ -467,57 +474,15 @@ __device__ int five_point_wave(SolveWs& w, const double* x1s, const double* x2s,
         w.c[i] = (t0 - t1) + t2;
     }
     __syncthreads();
-    const int nr = real_roots(w, 10, lane);
-
-    bool ok = false;
-    double E[9];
-    if (lane < nr) {
-        const double z = w.roots[lane];
-        double b[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            b[r][0] = horner(w.B[r][0], 3, z);
-            b[r][1] = horner(w.B[r][1], 3, z);
-            b[r][2] = horner(w.B[r][2], 4, z);
-        }
-        double bn0 = 0, bn1 = 0, bn2 = 0, bestz = -1.0;
-        const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const double* r0 = b[pr[q][0]];
-            const double* r1 = b[pr[q][1]];
-            const double nx = r0[1] * r1[2] - r0[2] * r1[1];
-            const double ny = r0[2] * r1[0] - r0[0] * r1[2];
-            const double nz = r0[0] * r1[1] - r0[1] * r1[0];
-            const double az = fabs(nz);
-            if (az > bestz) { bestz = az; bn0 = nx; bn1 = ny; bn2 = nz; }
-        }
-        const double nn = sqrt((bn0 * bn0 + bn1 * bn1) + bn2 * bn2);
-        if (nn > 0.0 && (bestz / nn >= 1e-10)) {
-            const double x = bn0 / bn2;
-            const double y = bn1 / bn2;
-            double s = 0.0;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                E[i] = ((x * w.N[i] + y * w.N[9 + i]) + z * w.N[18 + i]) + w.N[27 + i];
-                s = s + E[i] * E[i];
-            }
-            const double nrm = sqrt(s);
-            if (nrm > 0.0 && nrm <= DBL_MAX) {
-                ok = true;
-#pragma unroll
-                for (int i = 0; i < 9; ++i) E[i] = E[i] / nrm;
-            }
-        }
+    if (lane < 11) slot[FP_C + lane] = w.c[lane];
+    if (lane < 39) {
+        const int r = lane / 13, t = lane % 13;
+        slot[FP_B + lane] = t < 4 ? w.B[r][0][t] : (t < 8 ? w.B[r][1][t - 4] : w.B[r][2][t - 8]);
     }
-    const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
-    if (ok) {
-        double* dst = models + 9 * __popcll(mask & ((1ull << lane) - 1ull));
-#pragma unroll
-        for (int i = 0; i < 9; ++i) dst[i] = E[i];
-    }
-    return __popcll(mask);
+    if (lane < 36) slot[FP_N + lane] = w.N[lane];
+    return true;
 }
+
 
 
 // ---- seven-point solver, one THREAD per hypothesis -----------------------------
@@ -687,6 +652,172 @@ __device__ __forceinline__ bool real_root3_part(const double* cin, int k, double
         return k == 0;
     }
     return false;
+}
+
+// ---- five-point solver, second half ---------------------------------------------
+// Second half: real roots of the degree-10 polynomial and one model per root.
+// FOUR hypotheses per wavefront, 16 lanes each: a level of the root isolation
+// has at most 11 intervals, one per lane, so a wavefront given to a single
+// hypothesis leaves 53 lanes idle through the longest part of the solver.
+// Level k (roots of the (n-k)-th derivative) is spelled out per degree, with
+// the coefficients of the level in registers.
+struct Roots5Ws {
+    double D[4][11][12];  // per hypothesis: D[k][i], coefficient i of the derivative of degree k
+    double prev[4][12];
+    double cur[4][12];
+};
+
+template <int K>
+__device__ __forceinline__ void roots5_level(Roots5Ws& w, int g, int sl, bool live, int n, double B, int& mprev)
+{
+    bool has = false;
+    double r = 0.0;
+    const bool run = live && K <= n;  // a polynomial whose leading terms vanish stops at its own degree
+    if (run && sl <= mprev) {
+        double P[K + 1], dP[K];
+#pragma unroll
+        for (int i = 0; i <= K; ++i) P[i] = w.D[g][K][i];
+#pragma unroll
+        for (int i = 0; i < K; ++i) dP[i] = w.D[g][K - 1][i];
+        const int t = sl;
+        const double lo = (t == 0) ? -B : w.prev[g][t - 1];
+        const double hi = (t < mprev) ? w.prev[g][t] : B;
+        double cur[3] = {0.0, 0.0, 0.0};
+        int mcur = 0;
+        root_interval<K>(P, dP, lo, hi, B, t == mprev, t == 0 && mprev >= 1, t == mprev && mprev >= 1, cur, mcur);
+        has = mcur > 0;
+        r = cur[0];
+    }
+    const unsigned mine = (unsigned)(__builtin_amdgcn_ballot_w64(has) >> (16 * g)) & 0xFFFFu;
+    __syncthreads();
+    if (has) w.cur[g][__popc(mine & ((1u << sl) - 1u))] = r;
+    __syncthreads();
+    if (run) {
+        mprev = __popc(mine);
+        if (sl < mprev) w.prev[g][sl] = w.cur[g][sl];
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(64) ransac_roots5_kernel(const RansacProb* __restrict__ probs, int hyp0, int n_hyp)
+{
+    __shared__ Roots5Ws w;
+    const RansacProb pb = probs[blockIdx.y];
+    const int lane = threadIdx.x, g = lane >> 4, sl = lane & 15;
+    const int t = blockIdx.x * 4 + g;
+    const int hyp = hyp0 + t;
+    const bool valid = t < n_hyp && pb.nmodels[hyp] == -1;
+    double* slot = pb.models + (size_t)(valid ? hyp : hyp0) * 90;
+
+    // scaled coefficients, degree after dropping vanishing leading terms, root bound
+    double cmax = 0.0;
+    double cn[11];
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) {
+        cn[i] = valid ? slot[FP_C + i] : 0.0;
+        cmax = fmax(cmax, fabs(cn[i]));
+    }
+    bool live = valid && cmax > 0.0 && cmax <= DBL_MAX;
+    int n = 10;
+    double B = 0.0;
+    if (live) {
+#pragma unroll
+        for (int i = 0; i <= 10; ++i) cn[i] = cn[i] / cmax;
+        while (n > 0 && cn[n] == 0.0) --n;
+        if (n == 0) live = false;
+    }
+    if (live) {
+        double lead = cn[0];
+#pragma unroll
+        for (int i = 1; i <= 10; ++i) lead = (i == n) ? cn[i] : lead;
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+            if (i < n) B = fmax(B, fabs(cn[i] / lead));
+        B = 1.0 + B;
+        if (!(B < 1e25)) B = 1e25;
+#pragma unroll
+        for (int i = 0; i <= 10; ++i)
+            if (sl == i && i <= n) w.D[g][n][i] = cn[i];
+    }
+    __syncthreads();
+    // derivative chain, one rounding per step as in the sequential statement
+    for (int k = 10; k > 1; --k) {
+        if (live && k <= n && sl < k) w.D[g][k - 1][sl] = (double)(sl + 1) * w.D[g][k][sl + 1];
+        __syncthreads();
+    }
+    int mprev = 1;
+    if (live && sl == 0) w.prev[g][0] = -w.D[g][1][0] / w.D[g][1][1];
+    __syncthreads();
+    roots5_level<2>(w, g, sl, live, n, B, mprev);
+    roots5_level<3>(w, g, sl, live, n, B, mprev);
+    roots5_level<4>(w, g, sl, live, n, B, mprev);
+    roots5_level<5>(w, g, sl, live, n, B, mprev);
+    roots5_level<6>(w, g, sl, live, n, B, mprev);
+    roots5_level<7>(w, g, sl, live, n, B, mprev);
+    roots5_level<8>(w, g, sl, live, n, B, mprev);
+    roots5_level<9>(w, g, sl, live, n, B, mprev);
+    roots5_level<10>(w, g, sl, live, n, B, mprev);
+    const int nr = live ? mprev : 0;
+
+    // one lane per root: (x, y) from the null vector of B(z), the model, its norm
+    bool ok = false;
+    double E[9];
+    if (sl < nr) {
+        const double z = w.prev[g][sl];
+        double b[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double c0[4], c1[4], c2[5];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                c0[i] = slot[FP_B + 13 * r + i];
+                c1[i] = slot[FP_B + 13 * r + 4 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) c2[i] = slot[FP_B + 13 * r + 8 + i];
+            b[r][0] = horner_t<3>(c0, z);
+            b[r][1] = horner_t<3>(c1, z);
+            b[r][2] = horner_t<4>(c2, z);
+        }
+        double bn0 = 0, bn1 = 0, bn2 = 0, bestz = -1.0;
+        const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double* r0 = b[pr[q][0]];
+            const double* r1 = b[pr[q][1]];
+            const double nx = r0[1] * r1[2] - r0[2] * r1[1];
+            const double ny = r0[2] * r1[0] - r0[0] * r1[2];
+            const double nz = r0[0] * r1[1] - r0[1] * r1[0];
+            const double az = fabs(nz);
+            if (az > bestz) { bestz = az; bn0 = nx; bn1 = ny; bn2 = nz; }
+        }
+        const double nn = sqrt((bn0 * bn0 + bn1 * bn1) + bn2 * bn2);
+        if (nn > 0.0 && (bestz / nn >= 1e-10)) {
+            const double x = bn0 / bn2;
+            const double y = bn1 / bn2;
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                E[i] = ((x * slot[FP_N + i] + y * slot[FP_N + 9 + i]) + z * slot[FP_N + 18 + i]) + slot[FP_N + 27 + i];
+                s = s + E[i] * E[i];
+            }
+            const double nrm = sqrt(s);
+            if (nrm > 0.0 && nrm <= DBL_MAX) {
+                ok = true;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) E[i] = E[i] / nrm;
+            }
+        }
+    }
+    // every lane has read what it needs from the slot; the models overwrite it
+    const unsigned mine = (unsigned)(__builtin_amdgcn_ballot_w64(ok) >> (16 * g)) & 0xFFFFu;
+    __syncthreads();
+    if (ok) {
+        double* dst = slot + 9 * __popc(mine & ((1u << sl) - 1u));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dst[i] = E[i];
+    }
+    if (valid && sl == 0) pb.nmodels[hyp] = __popc(mine);
 }
 
 #define SFM_SA(i, j) sA[((i) * 9 + (j)) * 64 + lane]
@@ -1165,9 +1296,9 @@ __global__ void __launch_bounds__(64) ransac_solve_kernel(const RansacProb* __re
         sx2[lane] = pb.x2[2 * pt + comp];
     }
     __syncthreads();
-    double* models = pb.models + (size_t)hyp * 90;
-    const int nm = five_point_wave(ws, sx1, sx2, models, lane);
-    if (lane == 0) pb.nmodels[hyp] = nm;
+    double* slot = pb.models + (size_t)hyp * 90;
+    const bool ok = five_point_wave(ws, sx1, sx2, slot, lane);
+    if (lane == 0) pb.nmodels[hyp] = ok ? -1 : 0;  // -1: waiting for ransac_roots5_kernel
 }
 
 // Seven-point hypotheses, one thread each, in two kernels: the elimination
@@ -1826,8 +1957,10 @@ hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_pro
         hipLaunchKernelGGL(ransac_roots7_kernel, dim3((n_hyp + per_wg - 1) / per_wg, n_prob), dim3(ROOTS7_WAVES * 64),
                            0, s, probs, hyp0, n_hyp);
     }
-    else
+    else {
         hipLaunchKernelGGL(ransac_solve_kernel, dim3(n_hyp, n_prob), dim3(64), 0, s, probs, hyp0);
+        hipLaunchKernelGGL(ransac_roots5_kernel, dim3((n_hyp + 3) / 4, n_prob), dim3(64), 0, s, probs, hyp0, n_hyp);
+    }
     return hipGetLastError();
 }
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
