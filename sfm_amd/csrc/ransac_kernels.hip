@@ -117,40 +117,6 @@ __device__ __forceinline__ void tighten_open_interval(HornerF&& P, bool open_lo,
     }
 }
 
-// Newton with bisection safeguard to a fixed point; see the CPU statement of
-// the same iteration in oracle/ for the reasoning.
-__device__ double solve_bracket(const double* P, const double* dP, int n, double lo, double hi, bool lo_neg)
-{
-    double xl = lo_neg ? lo : hi;
-    double xh = lo_neg ? hi : lo;
-    double x = 0.5 * (lo + hi);
-    double dxold = fabs(hi - lo);
-    double dx = dxold;
-    double f = horner(P, n, x);
-    double df = horner(dP, n - 1, x);
-    for (int it = 0; it < 300; ++it) {
-        if (f == 0.0) return x;
-        if (f < 0.0) xl = x; else xh = x;
-        const bool bisect = (((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) ||
-                            (fabs(2.0 * f) > fabs(dxold * df));
-        dxold = dx;
-        double xn;
-        if (bisect) {
-            dx = 0.5 * (xh - xl);
-            xn = xl + dx;
-            if (xn == xl || xn == xh) return x;
-        } else {
-            dx = f / df;
-            xn = x - dx;
-            if (xn == x) return x;
-        }
-        x = xn;
-        f = horner(P, n, x);
-        df = horner(dP, n - 1, x);
-    }
-    return x;
-}
-
 // Per-wavefront workspace in LDS.
 struct SolveWs {
     double Q[7 * 9];
@@ -161,13 +127,7 @@ struct SolveWs {
     double B[3][3][5];
     double M[3][8];
     double c[11];
-    double cn[11];
-    double D[11][11];
-    double prev[12];
-    double cur[12];
-    double roots[12];
     int perm[9];
-    int has[12];
 };
 
 // Null space of the rows x 9 system in w.Q by Gauss-Jordan with complete
@@ -229,78 +189,6 @@ __device__ bool null_space_9(SolveWs& w, int rows, int lane)
     }
     __syncthreads();
     return true;
-}
-
-// All real roots, ascending, of w.c[0..n] (coefficient of z^i at index i).
-// Isolation by the roots of successive derivatives; intervals of one level are
-// solved by different lanes.  Result in w.roots, returns the count.
-__device__ int real_roots(SolveWs& w, int n, int lane)
-{
-    double cmax = 0.0;
-    for (int i = 0; i <= n; ++i) cmax = fmax(cmax, fabs(w.c[i]));
-    if (!(cmax > 0.0) || !(cmax <= DBL_MAX)) return 0;
-    __syncthreads();
-    if (lane <= n) w.cn[lane] = w.c[lane] / cmax;
-    __syncthreads();
-    while (n > 0 && w.cn[n] == 0.0) --n;
-    if (n == 0) return 0;
-    if (lane <= n) w.D[n][lane] = w.cn[lane];
-    __syncthreads();
-    for (int k = n; k > 1; --k) {
-        if (lane < k) w.D[k - 1][lane] = (double)(lane + 1) * w.D[k][lane + 1];
-        __syncthreads();
-    }
-    double B = 0.0;
-    for (int i = 0; i < n; ++i) B = fmax(B, fabs(w.cn[i] / w.cn[n]));
-    B = 1.0 + B;
-    if (!(B < 1e25)) B = 1e25;
-    if (lane == 0) w.prev[0] = -w.D[1][0] / w.D[1][1];
-    __syncthreads();
-    int mprev = 1;
-    if (n == 1) {
-        if (lane == 0) w.roots[0] = w.prev[0];
-        __syncthreads();
-        return 1;
-    }
-    for (int k = 2; k <= n; ++k) {
-        int has = 0;
-        double r = 0.0;
-        if (lane <= mprev) {
-            const int t = lane;
-            double lo = (t == 0) ? -B : w.prev[t - 1];
-            double hi = (t < mprev) ? w.prev[t] : B;
-            if (lo < -B) lo = -B;
-            if (lo > B) lo = B;
-            if (hi < -B) hi = -B;
-            if (hi > B) hi = B;
-            if (hi > lo) {
-                double flo = horner(w.D[k], k, lo);
-                double fhi = horner(w.D[k], k, hi);
-                tighten_open_interval([&](double x) { return horner(w.D[k], k, x); }, t == 0 && mprev >= 1,
-                                      t == mprev && mprev >= 1, lo, hi, flo, fhi);
-                if (flo == 0.0) {
-                    has = 1;
-                    r = lo;
-                } else if (fhi != 0.0 && ((flo < 0.0) != (fhi < 0.0))) {
-                    has = 1;
-                    r = solve_bracket(w.D[k], w.D[k - 1], k, lo, hi, flo < 0.0);
-                } else if (fhi == 0.0 && t == mprev) {
-                    has = 1;
-                    r = hi;
-                }
-            }
-        }
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(has != 0);
-        __syncthreads();
-        if (has) w.cur[__popcll(mask & ((1ull << lane) - 1ull))] = r;
-        __syncthreads();
-        mprev = __popcll(mask);
-        if (lane < mprev) w.prev[lane] = w.cur[lane];
-        __syncthreads();
-    }
-    if (lane < mprev) w.roots[lane] = w.prev[lane];
-    __syncthreads();
-    return mprev;
 }
 
 // Layout of what the first half of the five-point solver leaves in a
@@ -513,7 +401,9 @@ __device__ __forceinline__ double horner_t(const double* c, double x)
     return s;
 }
 
-// solve_bracket with compile-time degree (arrays stay in registers)
+// Newton with bisection safeguard run to a fixed point (see the CPU statement of
+// the same iteration in oracle/ for the reasoning); the degree is a compile-time
+// constant so that the coefficient arrays stay in registers.
 template <int N>
 __device__ __forceinline__ double solve_bracket_t(const double* P, const double* dP, double lo, double hi,
                                                   bool lo_neg)
@@ -556,7 +446,7 @@ __device__ __forceinline__ double clamp_b(double v, double B)
     return v;
 }
 
-// One interval of one level of real_roots(): P has degree K, dP is its
+// One interval of one level of the root isolation: P has degree K, dP is its
 // derivative; appends at most one root to cur[0..2].
 template <int K>
 __device__ __forceinline__ void root_interval(const double* P, const double* dP, double lo, double hi, double B,
