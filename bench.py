@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--no-microkernel", action="store_true", help="skip the MFMA-only ceiling launches")
     ap.add_argument("--knn-variant", type=int, default=-1, help="debug: force the sweep kernel shape")
     ap.add_argument("--score-filter", type=int, default=1, help="debug: 0 = double precision only")
+    ap.add_argument("--score-prune", type=int, default=1, help="debug: 0 = score every model on every point")
     args = ap.parse_args()
 
     import torch
@@ -111,6 +112,8 @@ def main():
         ctx._L.sfm_gpu_debug_set_knn_variant(ctx.handle, args.knn_variant)
     if args.score_filter != 1:
         ctx._L.sfm_gpu_debug_set_score_filter(args.score_filter)
+    if args.score_prune != 1:
+        ctx._L.sfm_gpu_debug_set_score_prune(args.score_prune)
     desc_ptrs = [d_desc[i].data_ptr() for i in range(2 * B)]
     kp_ptrs = [d_kp[i].data_ptr() for i in range(2 * B)]
     packed_ptrs = [d_packed[i].data_ptr() for i in range(2 * B)]

@@ -1879,10 +1879,11 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     if (prune && g_score_prune && n_chunks > s1) {
         score(chunk / 2, 0, 2 * s1, groups, s1 * chunk);
         hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, s1 * chunk);
-        // the survivors are few: short chunks, and a grid a quarter of the list
-        // wide and at most 16 chunks deep that strides over whatever is left
+        // the survivors are few: quarter chunks, and a grid an eighth of the list
+        // wide and at most 32 chunks deep that strides over whatever is left
+        // (measured best among widths 1/2..1/16 and depths 8..32)
         const int rest = (n_chunks - s1) * 4;
-        score(chunk / 4, s1 * 4, rest < 16 ? rest : 16, (groups + 3) / 4, INT_MAX);
+        score(chunk / 4, s1 * 4, rest < 32 ? rest : 32, (groups + 7) / 8, INT_MAX);
     } else {
         score(chunk, 0, n_chunks, groups, INT_MAX);
     }
