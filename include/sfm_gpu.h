@@ -117,8 +117,10 @@ int sfm_gpu_ratio_test(const sfm_gpu_dmatch* matches, const int32_t* counts, int
  *   threshold_px  inlier threshold in pixels        (1.0 at main.cpp:224)
  *   max_iters     iteration cap of the adaptive loop (OpenCV default 1000)
  *   mode          SFM_GPU_RANSAC_ADAPTIVE reproduces OpenCV's sequential,
- *                 self-shortening loop; SFM_GPU_RANSAC_FIXED scores exactly
- *                 n_hyp hypotheses
+ *                 self-shortening loop; SFM_GPU_RANSAC_FIXED solves exactly
+ *                 n_hyp hypotheses and returns what scoring every one of their
+ *                 models on every point returns (models that provably cannot
+ *                 reach the best count are not scored to the end)
  *   sample_table  host, optional n_hyp x m int32 point indices (m = 5 or 7),
  *                 FIXED mode only; NULL: the library's own seeded table, whose
  *                 rows are independent draws of a counter-based generator
