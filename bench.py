@@ -213,7 +213,7 @@ def main():
             "config": {
                 "workload": "configs[1]: pairs of %dx%d SIFT-like descriptors, kNN k=2 + ratio 0.7 + "
                             "fundamental RANSAC %d hyps (fixed count)" % (n, n, nh),
-                "pairs_per_step": B,
+                "pairs_per_step": B * world,
                 "pairs_per_gpu_per_step": B,
                 "n_good_mean": float(np.mean(n_good)),
                 "n_inliers_mean": float(np.mean(n_inl)),
@@ -244,7 +244,7 @@ def main():
             },
             "kernels_outside_timed_region": kern,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg belongs to the single-GPU line only
             threads = int(os.environ.get("OMP_NUM_THREADS", "8"))
             threads = max(1, min(threads, 64))
             cb = cpu_baseline(descs, kps, nh, threads, min(B, 16))
