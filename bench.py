@@ -93,10 +93,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    # SFM_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with
+    # fewer GPUs than ranks (ranks then share devices); the real run is RCCL.
+    backend = os.environ.get("SFM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     B, n, nh = args.pairs_per_step, args.n_desc, args.hyps
     descs, kps = make_pairs(B, n, 1000 + 100000 * rank, args.wrong_frac)
@@ -176,7 +184,7 @@ def main():
     ctx.profile_enable(False)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
