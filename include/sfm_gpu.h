@@ -163,6 +163,34 @@ int sfm_gpu_recover_pose(sfm_gpu_ctx* ctx, const double* E, const double* pts1,
                          const double* pts2, int n, const double* K, double distance_thresh,
                          double* R_out, double* t_out, uint8_t* mask, int32_t* n_good);
 
+/* ---- three-view track join: replaces main.cpp:442-456 ----------------- */
+
+/* Keypoint indices of one track in images i, i+1 and j. */
+typedef struct sfm_gpu_track3 {
+    int32_t a, b, c;
+} sfm_gpu_track3;
+
+/*
+ * The nested loop of main.cpp:442-456 over matches[i] (pair (i, i+1)) and
+ * matches[i+1] (pair (i+1, j)): every (m, n) with
+ * matches_ab[m].trainIdx == matches_bc[n].queryIdx gives the triple
+ * (matches_ab[m].queryIdx, matches_ab[m].trainIdx, matches_bc[n].trainIdx), in
+ * the order of that loop (m outer, n inner) -- the indices of kp1, kp2, kp3.
+ *
+ *   matches_ab, matches_bc   host, any order for ab; bc in ascending queryIdx
+ *                            (equal values allowed), which is how match()
+ *                            (main.cpp:189-231) and sfm_gpu_match_pairs emit it;
+ *                            SFM_GPU_ERR_UNSUPPORTED otherwise
+ *   tracks, capacity         out, room for `capacity` triples
+ *   n_tracks                 out, number of triples found; when it exceeds
+ *                            capacity the call returns SFM_GPU_ERR_CAPACITY and
+ *                            writes none
+ * The reference spends O(n_ab * n_bc) here; this is a bisection join.
+ */
+int sfm_gpu_track_join(sfm_gpu_ctx* ctx, const sfm_gpu_dmatch* matches_ab, int n_ab,
+                       const sfm_gpu_dmatch* matches_bc, int n_bc, sfm_gpu_track3* tracks,
+                       int capacity, int32_t* n_tracks);
+
 /* ---- device-resident images: the all-pairs driver --------------------- */
 
 /*
@@ -257,7 +285,7 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
  * query returns accumulated milliseconds and launch count since the last
  * reset.  Kernel names: "knn2_mfma", "prep_rows", "knn_finalize",
  * "ratio_compact", "ransac_table", "ransac_solve", "ransac_score",
- * "ransac_select", "pose_vote".  Has no counterpart in the reference.
+ * "ransac_select", "pose_vote", "track_join".  Has no counterpart in the reference.
  */
 int sfm_gpu_profile_enable(sfm_gpu_ctx* ctx, int on);
 /* Restricts the timing to one named kernel (NULL: all of them), so that a

@@ -65,6 +65,8 @@ def lib():
         L.oracle_decompose_essential.restype = c.c_int
         L.oracle_recover_pose.argtypes = [vp, vp, vp, c.c_int, vp, c.c_double, vp, vp, vp, vp]
         L.oracle_recover_pose.restype = c.c_int
+        L.oracle_track_join.argtypes = [vp, c.c_int, vp, c.c_int, vp, c.c_int]
+        L.oracle_track_join.restype = c.c_int
         _lib = L
     return _lib
 
@@ -244,3 +246,16 @@ def recover_pose(E, pts1, pts2, K, distance_thresh=50.0, mask=None):
     good = lib().oracle_recover_pose(_p(E), _p(pts1), _p(pts2), n, _p(Kc), distance_thresh,
                                      _p(R), _p(t), _p(m), _p(votes))
     return dict(n_good=good, R=R, t=t, mask=m, votes=votes)
+
+
+def track_join(ab, bc):
+    """ab, bc: DMATCH_DTYPE arrays.  Returns the [n, 3] int32 triples of
+    main.cpp:442-456 in the reference's loop order."""
+    ab = np.ascontiguousarray(ab, dtype=DMATCH_DTYPE)
+    bc = np.ascontiguousarray(bc, dtype=DMATCH_DTYPE)
+    n = lib().oracle_track_join(_p(ab), len(ab), _p(bc), len(bc), None, 0)
+    assert n >= 0
+    out = np.zeros((n, 3), dtype=np.int32)
+    got = lib().oracle_track_join(_p(ab), len(ab), _p(bc), len(bc), _p(out), n)
+    assert got == n
+    return out

@@ -860,6 +860,26 @@ int cheirality_vote(const double* R, const double* t, double x1, double y1, doub
 
 extern "C" {
 
+int oracle_track_join(const oracle_dmatch* ab, int n_ab, const oracle_dmatch* bc, int n_bc, int32_t* out,
+                      int capacity)
+{
+    // /root/reference/main.cpp:442-456, loop for loop: every (m, n) with
+    // matches[i][m].trainIdx == matches[i+1][n].queryIdx, m outer, n inner.
+    if (n_ab < 0 || n_bc < 0 || (n_ab > 0 && !ab) || (n_bc > 0 && !bc)) return -1;
+    int count = 0;
+    for (int m = 0; m < n_ab; m++)
+        for (int n = 0; n < n_bc; n++)
+            if (ab[m].trainIdx == bc[n].queryIdx) {
+                if (out && count < capacity) {
+                    out[3 * count + 0] = ab[m].queryIdx;
+                    out[3 * count + 1] = ab[m].trainIdx;
+                    out[3 * count + 2] = bc[n].trainIdx;
+                }
+                count++;
+            }
+    return count;
+}
+
 int oracle_svd3(const double* A, double* U, double* S, double* V) { return svd3_jacobi(A, U, S, V); }
 
 int oracle_decompose_essential(const double* E, double* R1, double* R2, double* t)

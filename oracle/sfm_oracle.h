@@ -153,6 +153,18 @@ int oracle_recover_pose(const double* E, const double* pts1, const double* pts2,
                         const double* K, double distance_thresh, double* R_out, double* t_out,
                         uint8_t* mask, int32_t* votes);
 
+/*
+ * The three-view join of /root/reference/main.cpp:442-456: for the inlier
+ * matches ab of image pair (i, i+1) and bc of pair (i+1, j), every (m, n) with
+ * ab[m].trainIdx == bc[n].queryIdx, in the order of the reference's nested loop
+ * (m outer, n inner).  out receives (ab[m].queryIdx, ab[m].trainIdx,
+ * bc[n].trainIdx) triples: the keypoint of one track in images i, i+1 and j.
+ * Returns the number of triples (which may exceed capacity; only `capacity`
+ * are written), -1 on bad arguments.  O(n_ab * n_bc) like the reference.
+ */
+int oracle_track_join(const oracle_dmatch* ab, int n_ab, const oracle_dmatch* bc, int n_bc, int32_t* out,
+                      int capacity);
+
 #ifdef __cplusplus
 }
 #endif

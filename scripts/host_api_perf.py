@@ -51,6 +51,26 @@ def main():
             assert o["n_good"] == ng and (o["mask"] == pm).all()
         print("n=%d: recoverPose(%d pts) %.3f ms host call, vote kernel %.1f us, %d in front%s" %
               (n, len(p1), t_pose * 1e3, k_ms * 1e3, ng, extra))
+        # three-view join (main.cpp:442-456) on lists of the size this pair produced
+        rng = np.random.default_rng(n)
+        m3 = int(mask.sum())
+        ab = np.zeros(m3, matcher.DMATCH_DTYPE); bc = np.zeros(m3, matcher.DMATCH_DTYPE)
+        ab["queryIdx"] = np.sort(rng.choice(n, m3, replace=False)); ab["trainIdx"] = rng.choice(n, m3, replace=False)
+        bc["queryIdx"] = np.sort(rng.choice(n, m3, replace=False)); bc["trainIdx"] = rng.choice(n, m3, replace=False)
+        for _ in range(2):
+            tr = matcher.track_join(ctx, ab, bc)
+        t0 = time.perf_counter()
+        for _ in range(reps * 4):
+            tr = matcher.track_join(ctx, ab, bc)
+        t_join = (time.perf_counter() - t0) / (reps * 4)
+        extra = ""
+        if os.environ.get("ORACLE"):
+            from oracle import pyoracle as po
+            t0 = time.perf_counter()
+            otr = po.track_join(ab, bc)
+            extra = "; CPU nested loop (oracle, twice: count + fill) %.2f ms" % ((time.perf_counter() - t0) * 1e3)
+            assert (otr == tr).all()
+        print("n=%d: track_join(%d x %d matches) %.3f ms host call, %d tracks%s" % (n, m3, m3, t_join * 1e3, len(tr), extra))
         mb = 2 * n * 128 * 4 / 1e6
         print("n=%d: knnMatch(host f32, %.0f MB up) %.2f ms; findEssentialMat(%d pts, adaptive) %.2f ms, "
               "%d iterations, %d inliers" % (n, mb, t_knn * 1e3, len(p1), t_rs * 1e3, r["iters"], r["n_inliers"]))

@@ -97,6 +97,7 @@ def lib():
     L.sfm_gpu_debug_set_score_filter.argtypes = [c.c_int]
     L.sfm_gpu_debug_pose_votes.argtypes = [vp, vp]
     L.sfm_gpu_debug_set_score_prune.argtypes = [c.c_int]
+    L.sfm_gpu_track_join.argtypes = [vp, vp, c.c_int, vp, c.c_int, vp, c.c_int, vp]
     L.sfm_gpu_recover_pose.argtypes = [vp, vp, vp, vp, c.c_int, vp, c.c_double, vp, vp, vp, vp]
     _lib = L
     return L

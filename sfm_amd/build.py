@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsfm_gpu.so")
 SOURCES = ["sfm_gpu_api.hip", "knn_kernels.hip", "ransac_kernels.hip", "pair_kernels.hip",
-           "ransac_api.hip", "pose.hip"]
+           "ransac_api.hip", "pose.hip", "tracks.hip"]
 # -ffp-contract=off: the RANSAC kernels must round exactly like unfused IEEE
 # double arithmetic so that inlier masks can be compared bit-for-bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

@@ -203,6 +203,24 @@ def recoverPose(ctx, E, points1, points2, cameraMatrix, distanceThresh=50.0, mas
     return good.value, R, t, m
 
 
+def track_join(ctx, matches_ab, matches_bc, capacity=None):
+    """The three-view join of main.cpp:442-456: [n, 3] int32 keypoint indices
+    (image i, image i+1, image j), in the reference's loop order.  matches_bc
+    must be in ascending queryIdx order (match() emits it so)."""
+    ab = np.ascontiguousarray(matches_ab, dtype=DMATCH_DTYPE).reshape(-1)
+    bc = np.ascontiguousarray(matches_bc, dtype=DMATCH_DTYPE).reshape(-1)
+    if capacity is None:
+        capacity = max(len(ab), 1)
+    out = np.zeros((capacity, 3), dtype=np.int32)
+    n = ctypes.c_int32(0)
+    rc = ctx._L.sfm_gpu_track_join(ctx.handle, ptr(ab), len(ab), ptr(bc), len(bc), ptr(out), capacity,
+                                   ctypes.byref(n))
+    if rc == _lib.ERR_CAPACITY and capacity < n.value:
+        return track_join(ctx, ab, bc, capacity=n.value)   # duplicates in bc: more triples than matches
+    ctx.check(rc)
+    return out[:n.value].copy()
+
+
 def pose_votes(ctx):
     """Vote counts of the four candidates in the last recoverPose call."""
     v = np.zeros(4, dtype=np.int32)

@@ -9,7 +9,7 @@ a diff against history and (b) the GPU path is checked against bytes that do
 not depend on the oracle being rebuilt.  Inputs are stored too, so the files
 are self-contained.
 
-    python tests/golden/make_golden.py [knn] [essential] [fundamental] [pose]
+    python tests/golden/make_golden.py [knn] [essential] [fundamental] [pose] [tracks]
 """
 import os
 import sys
@@ -68,8 +68,27 @@ def pose_case():
         near_mask=near["mask"], near_votes=near["votes"])
 
 
+def tracks_case():
+    """Inlier matches of two consecutive pairs of a three-image ring, joined as
+    at main.cpp:442-456 (plus two repeated query rows in the second list)."""
+    rng = np.random.default_rng(31)
+    n_kp = 900
+    ab = np.zeros(420, dtype=po.DMATCH_DTYPE)
+    ab["queryIdx"] = np.sort(rng.choice(n_kp, 420, replace=False))
+    ab["trainIdx"] = rng.choice(n_kp, 420, replace=False)
+    bc = np.zeros(380, dtype=po.DMATCH_DTYPE)
+    q = np.sort(rng.choice(n_kp, 380, replace=False))
+    q[7] = q[6]
+    q[200] = q[199]
+    bc["queryIdx"] = q
+    bc["trainIdx"] = rng.choice(n_kp, 380, replace=False)
+    t = po.track_join(ab, bc)
+    np.savez_compressed(os.path.join(HERE, "track_join.npz"), ab_query=ab["queryIdx"], ab_train=ab["trainIdx"],
+                        bc_query=bc["queryIdx"], bc_train=bc["trainIdx"], tracks=t)
+
+
 def main():
-    which = sys.argv[1:] or ["knn", "essential", "fundamental", "pose"]
+    which = sys.argv[1:] or ["knn", "essential", "fundamental", "pose", "tracks"]
     if "knn" in which:
         knn_case()
     if "essential" in which:
@@ -78,6 +97,8 @@ def main():
         ransac_case("ransac_fundamental.npz", po.MODEL_FUNDAMENTAL, 500, 22, 128)
     if "pose" in which:
         pose_case()
+    if "tracks" in which:
+        tracks_case()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -57,6 +57,20 @@ def test_oracle_reproduces_pose_golden(oracle):
     assert (n["mask"] == g["near_mask"]).all() and (n["votes"] == g["near_votes"]).all()
 
 
+def _track_lists(g, dtype):
+    ab = np.zeros(len(g["ab_query"]), dtype=dtype)
+    ab["queryIdx"], ab["trainIdx"] = g["ab_query"], g["ab_train"]
+    bc = np.zeros(len(g["bc_query"]), dtype=dtype)
+    bc["queryIdx"], bc["trainIdx"] = g["bc_query"], g["bc_train"]
+    return ab, bc
+
+
+def test_oracle_reproduces_track_golden(oracle):
+    g = load("track_join.npz")
+    ab, bc = _track_lists(g, oracle.DMATCH_DTYPE)
+    assert (oracle.track_join(ab, bc) == g["tracks"]).all() and len(g["tracks"]) > 100
+
+
 # ---- GPU: the HIP path against the same bytes -----------------------------
 
 @pytest.mark.gpu
@@ -113,3 +127,12 @@ def test_gpu_pose_equals_golden(gpu_ctx):
     # the chain of main.cpp:418-420 on the GPU gives the same E, hence the same pose
     E, _, r = matcher.findEssentialMat(gpu_ctx, g["pts1"], g["pts2"], g["K"], prob=0.999, threshold=1.0)
     assert (np.asarray(E).view(np.uint64) == g["E"].view(np.uint64)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_track_join_equals_golden(gpu_ctx):
+    from sfm_amd import matcher
+    g = load("track_join.npz")
+    ab, bc = _track_lists(g, matcher.DMATCH_DTYPE)
+    t = matcher.track_join(gpu_ctx, ab, bc)
+    assert t.shape == g["tracks"].shape and (t == g["tracks"]).all()

@@ -330,3 +330,32 @@ def test_recover_pose_mask_and_distance(oracle):
     none = oracle.recover_pose(E, np.zeros((0, 2)), np.zeros((0, 2)), K)
     assert none["n_good"] == 0 and (none["R"] == R1).all() and (none["t"] == tt).all()
     assert oracle.recover_pose(np.zeros((3, 3)), p1, p2, K)["n_good"] == -1
+
+
+# ---- three-view track join (main.cpp:442-456) -----------------------------
+
+def _dm(q, t):
+    m = np.zeros(len(q), dtype=pyoracle_dtype())
+    m["queryIdx"] = q
+    m["trainIdx"] = t
+    return m
+
+
+def pyoracle_dtype():
+    from oracle import pyoracle
+    return pyoracle.DMATCH_DTYPE
+
+
+def test_track_join_is_the_nested_loop(oracle):
+    ab = _dm([10, 11, 12, 13], [5, 3, 9, 3])
+    bc = _dm([3, 3, 5, 7, 9], [100, 101, 102, 103, 104])
+    assert oracle.track_join(ab, bc).tolist() == [[10, 5, 102], [11, 3, 100], [11, 3, 101], [12, 9, 104],
+                                                  [13, 3, 100], [13, 3, 101]]
+    assert oracle.track_join(ab[:0], bc).shape == (0, 3) and oracle.track_join(ab, bc[:0]).shape == (0, 3)
+    # against a literal Python statement of the loop on random (unsorted, repeating) lists
+    rng = np.random.default_rng(4)
+    a = _dm(rng.integers(0, 50, 80), rng.integers(0, 40, 80))
+    b = _dm(rng.integers(0, 40, 70), rng.integers(0, 60, 70))
+    want = [[int(x["queryIdx"]), int(x["trainIdx"]), int(y["trainIdx"])] for x in a for y in b
+            if x["trainIdx"] == y["queryIdx"]]
+    assert oracle.track_join(a, b).tolist() == want
