@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--knn-variant", type=int, default=-1, help="debug: force the sweep kernel shape")
     ap.add_argument("--score-filter", type=int, default=1, help="debug: 0 = double precision only")
     ap.add_argument("--score-prune", type=int, default=1, help="debug: 0 = score every model on every point")
+    ap.add_argument("--desc-u8", action="store_true",
+                    help="descriptors arrive as CV_8U instead of cv::SIFT's CV_32F (not the headline configuration)")
     args = ap.parse_args()
 
     import torch
@@ -110,7 +112,10 @@ def main():
     descs, kps = make_pairs(B, n, 1000 + 100000 * rank, args.wrong_frac)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        d_desc = torch.from_numpy(np.stack(descs)).cuda()          # [2B, n, 128] float32
+        host_desc = np.stack(descs)
+        if args.desc_u8:
+            host_desc = host_desc.astype(np.uint8)
+        d_desc = torch.from_numpy(host_desc).cuda()                # [2B, n, 128] float32 (or uint8)
         d_kp = torch.from_numpy(np.stack(kps)).cuda()              # [2B, n, 2] float32
         blk = matcher.image_packed_bytes(n)
         d_packed = torch.empty((2 * B, blk), dtype=torch.uint8, device="cuda")
@@ -128,11 +133,11 @@ def main():
     images = [matcher.WrappedImage(ctx, packed_ptrs[i], n) for i in range(2 * B)]
     pairs = np.array([[2 * p, 2 * p + 1] for p in range(B)], np.int32)
 
-    row_bytes = 128 * 4  # float32 descriptors, densely packed
+    row_bytes = 128 * (1 if args.desc_u8 else 4)  # densely packed rows
+    desc_dtype = matcher.DESC_U8 if args.desc_u8 else matcher.DESC_F32
 
     def step():
-        matcher.prepare_many(ctx, desc_ptrs, [n] * (2 * B), row_bytes, matcher.DESC_F32, kp_ptrs,
-                             packed_ptrs)
+        matcher.prepare_many(ctx, desc_ptrs, [n] * (2 * B), row_bytes, desc_dtype, kp_ptrs, packed_ptrs)
         return matcher.match_pairs(ctx, images, pairs, None, ratio=0.7,
                                    model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED,
                                    prob=0.99, threshold=3.0, n_hyp=nh)
@@ -219,8 +224,9 @@ def main():
             "dtype": "int8 MFMA / int32 accumulate (kNN), f64 (RANSAC)",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: pairs of %dx%d SIFT-like descriptors, kNN k=2 + ratio 0.7 + "
-                            "fundamental RANSAC %d hyps (fixed count)" % (n, n, nh),
+                "workload": "configs[1]: pairs of %dx%d SIFT-like descriptors (%s), kNN k=2 + ratio 0.7 + "
+                            "fundamental RANSAC %d hyps (fixed count)" %
+                            (n, n, "CV_8U" if args.desc_u8 else "CV_32F as cv::SIFT emits them", nh),
                 "pairs_per_step": B * world,
                 "pairs_per_gpu_per_step": B,
                 "n_good_mean": float(np.mean(n_good)),

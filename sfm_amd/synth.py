@@ -122,3 +122,39 @@ def keypoints_for_pair(n_query, n_train, planted, seed, noise_px=0.5, K=REF_K, w
     else:
         kt[planted[rows]] = p2
     return kq.astype(np.float32), kt.astype(np.float32)
+
+
+def image_sequence(n_img, n_kp, seed, shared=0.5, sigma=6.0, noise_px=0.5, K=REF_K):
+    """A consistent multi-view sequence (the shape of the reference's data/
+    set): one pool of 3-D points with one base descriptor each, cameras moving
+    along a baseline with a small rotation per step; every image shows
+    `shared` of its n_kp rows from the pool (noisy copies of the descriptors,
+    noisy projections) and random rows otherwise.  Returns (descs, kps, ids)
+    with ids[i][row] = pool index of the row or -1."""
+    rng = np.random.default_rng(seed)
+    n_world = int(n_kp * shared * 2)
+    base = sift_like(n_world, seed + 1)
+    Kinv = np.linalg.inv(K)
+    px = np.stack([rng.uniform(-200, IMG_W + 200, n_world), rng.uniform(0, IMG_H, n_world), np.ones(n_world)], 1)
+    X = (px @ Kinv.T) * rng.uniform(425.0, 935.0, n_world)[:, None]
+    descs, kps, ids = [], [], []
+    for i in range(n_img):
+        R = _rot(np.array([0.1, 1.0, 0.05]), np.deg2rad(0.8 * i))
+        t = np.array([-12.0 * i, 0.5 * i, 1.0 * i])
+        Xc = X @ R.T + t
+        p = Xc @ K.T
+        p = p[:, :2] / p[:, 2:]
+        vis = np.flatnonzero((p[:, 0] >= 0) & (p[:, 0] < IMG_W) & (p[:, 1] >= 0) & (p[:, 1] < IMG_H) & (Xc[:, 2] > 0))
+        n_sh = min(int(n_kp * shared), len(vis))
+        pick = rng.permutation(vis)[:n_sh]
+        d = sift_like(n_kp, seed + 100 + i)
+        k = np.stack([rng.uniform(0, IMG_W, n_kp), rng.uniform(0, IMG_H, n_kp)], 1)
+        wid = np.full(n_kp, -1, dtype=np.int64)
+        rows = rng.permutation(n_kp)[:n_sh]
+        d[rows] = np.clip(base[pick] + np.rint(rng.normal(0.0, sigma, (n_sh, 128))), 0, 255).astype(np.float32)
+        k[rows] = p[pick] + rng.normal(0.0, noise_px, (n_sh, 2))
+        wid[rows] = pick
+        descs.append(d)
+        kps.append(k.astype(np.float32))
+        ids.append(wid)
+    return descs, kps, ids

@@ -89,3 +89,36 @@ def test_track_join_limits(gpu_ctx):
     assert L.sfm_gpu_track_join(gpu_ctx.handle, None, 5, bc.ctypes.data, len(bc), out.ctypes.data, 2,
                                 ctypes.byref(n)) == -1
     assert (matcher.track_join(gpu_ctx, ab, bc) == full).all()
+
+
+def test_sequence_from_blobs_gives_world_tracks(gpu_ctx, oracle, tmp_path):
+    """The chain the reference runs (match() ring, then the three-view join) from
+    descriptor blobs on disk: the tracks found are the planted world points."""
+    from sfm_amd import blob, matcher, synth
+    descs, kps, ids = synth.image_sequence(4, 1500, 9)
+    for i in range(4):
+        blob.write_blob(str(tmp_path / ("img_%d.sfmd" % i)), descs[i].astype(np.uint8) if i % 2 else descs[i],
+                        kps[i], synth.REF_K)
+    blobs = [blob.read_blob(str(tmp_path / ("img_%d.sfmd" % i))) for i in range(4)]
+    imgs = [matcher.Image(gpu_ctx, np.ascontiguousarray(b["descriptors"]), np.ascontiguousarray(b["keypoints"]))
+            for b in blobs]
+    pairs = np.array([[0, 1], [1, 2], [2, 3]], np.int32)
+    n_good, n_inl, sel = matcher.match_pairs(gpu_ctx, imgs, pairs, blobs[0]["K"], prob=0.99, threshold=1.0,
+                                             want_matches=True)
+    for p, (i, j) in enumerate(pairs.tolist()):
+        # the same pair through the oracle, call by call
+        m, c = oracle.knn_match(descs[i], descs[j], 2)
+        keep = oracle.ratio_test(m, c, 0.7)
+        good = m[keep, 0]
+        r = oracle.ransac(kps[i][good["queryIdx"]].astype(np.float64), kps[j][good["trainIdx"]].astype(np.float64),
+                          synth.REF_K, prob=0.99, threshold=1.0)
+        want = good[r["mask"] != 0]
+        assert n_good[p] == len(good) and n_inl[p] == len(want)
+        assert (sel[p]["queryIdx"] == want["queryIdx"]).all() and (sel[p]["trainIdx"] == want["trainIdx"]).all()
+    for p in range(2):
+        tr = matcher.track_join(gpu_ctx, sel[p], sel[p + 1])
+        assert (tr == oracle.track_join(sel[p], sel[p + 1])).all() and len(tr) > 100
+        a, b, c = ids[p][tr[:, 0]], ids[p + 1][tr[:, 1]], ids[p + 2][tr[:, 2]]
+        assert (a == b).all() and (b == c).all() and (a >= 0).all()
+    for im in imgs:
+        im.close()
