@@ -45,7 +45,9 @@ int sfm_gpu_debug_sqrt_probe(sfm_gpu_ctx* ctx, int32_t* mismatches);
 /* 0: the RANSAC scoring kernel evaluates every (model, point) pair in double
  * precision only; 1 (default): a float32 filter with a rigorous error bound
  * settles the clear cases first.  Both give identical counts; the switch lets
- * tests prove it.  Process-wide. */
+ * tests prove it.  2 and 3 are timing experiments with WRONG counts (2: tests
+ * the filter cannot settle are dropped; 3: also no point loads inside the
+ * loop).  Process-wide. */
 int sfm_gpu_debug_set_score_filter(int on);
 
 /* Fixed-count RANSAC scores its candidate models in stages over the points and,
