@@ -1542,7 +1542,7 @@ __device__ __forceinline__ f2v filter_h_out(const PairTerms& t, const FilterCons
 // workgroup strides over further groups / chunks when the grid is smaller than
 // the work, keeping its models in registers from chunk to chunk.
 constexpr int SCORE_WAVES = 1;  // independent wavefronts per workgroup
-template <int MODEL>
+template <int MODEL, bool STRIDED>
 __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const RansacProb* __restrict__ probs, int chunk_pts,
                                                           int use_filter, int chunk0, int pts_end)
 {
@@ -1556,7 +1556,7 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
     const int n = min(__builtin_amdgcn_readfirstlane(*pb.n_ptr), pts_end);
     if ((chunk0 + (int)blockIdx.y) * chunk_pts >= n) return;  // chunk_pts is a multiple of 4
     const int lane = threadIdx.x & 63;
-    constexpr int QCAP = 16;
+    constexpr int QCAP = 40;
     __shared__ unsigned short parked_all[SCORE_WAVES * QCAP * 64];
     unsigned short* parked = parked_all + wv * (QCAP * 64);
     for (int g0 = (blockIdx.x * SCORE_WAVES + wv) * 64; g0 < nlist; g0 += gridDim.x * SCORE_WAVES * 64) {
@@ -1614,11 +1614,7 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
             f2v cur[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) cur[k] = nx[k];
-            // the loads of the next block go out before this block's arithmetic
-            // starts, so that they have the whole step to arrive
-            __builtin_amdgcn_sched_barrier(0);
-            if (use_filter != 3) fetch(i + 4 < i4 ? i + 4 : i);  // the last step re-reads its own points
-            __builtin_amdgcn_sched_barrier(0);
+            fetch(i + 4 < i4 ? i + 4 : i);  // the last step re-reads its own points
             const PairTerms tA = filter_terms<MODEL>(Mf, cur[0], cur[2], cur[4], cur[6]);
             const PairTerms tB = filter_terms<MODEL>(Mf, cur[1], cur[3], cur[5], cur[7]);
             const f2v hinA = filter_h_in(tA, fc), hinB = filter_h_in(tB, fc);
@@ -1640,8 +1636,10 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
     }
     for (; i < i1; ++i) cnt += exact(i);
     for (int k = 0; k < n_parked; ++k) cnt += exact(i0 + (int)parked[k * 64 + lane]);
+    if (!STRIDED) break;  // the grid covers every chunk: straight-line code
     }  // chunks
     if (active && cnt != 0) atomicAdd(&pb.counts[e], cnt);
+    if (!STRIDED) break;
     }  // groups
 }
 
@@ -1861,14 +1859,25 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     const int chunk = 512;
     const int n_chunks = (cap + chunk - 1) / chunk > 0 ? (cap + chunk - 1) / chunk : 1;
     const unsigned groups = (unsigned)(((size_t)n_hyp * maxm + 63) / 64);
-    auto score = [&](int chunk_pts, int chunk0, int chunks, unsigned gx, int pts_end) {
-        const dim3 grid((gx + SCORE_WAVES - 1) / SCORE_WAVES, chunks, n_prob);
-        if (model == SFM_GPU_MODEL_ESSENTIAL)
-            hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL>, grid, dim3(SCORE_WAVES * 64), 0, s, probs,
-                               chunk_pts, g_score_filter, chunk0, pts_end);
-        else
-            hipLaunchKernelGGL(ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL>, grid, dim3(SCORE_WAVES * 64), 0, s, probs,
-                               chunk_pts, g_score_filter, chunk0, pts_end);
+    // strided: the grid is smaller than the work and its workgroups loop
+    auto score = [&](int chunk_pts, int chunk0, int chunks, unsigned gx, int pts_end, bool strided) {
+        const dim3 grid((gx + SCORE_WAVES - 1) / SCORE_WAVES, chunks, n_prob), block(SCORE_WAVES * 64);
+        const int f = g_score_filter;
+        if (model == SFM_GPU_MODEL_ESSENTIAL) {
+            if (strided)
+                hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL, true>), grid, block, 0, s, probs,
+                                   chunk_pts, f, chunk0, pts_end);
+            else
+                hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL, false>), grid, block, 0, s, probs,
+                                   chunk_pts, f, chunk0, pts_end);
+        } else {
+            if (strided)
+                hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL, true>), grid, block, 0, s, probs,
+                                   chunk_pts, f, chunk0, pts_end);
+            else
+                hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL, false>), grid, block, 0, s, probs,
+                                   chunk_pts, f, chunk0, pts_end);
+        }
     };
     // Two stages with a pruning step between them: every model on the first
     // 1/prune of the capacity (in half chunks: a single round of workgroups
@@ -1877,15 +1886,15 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     // points, the normal case behind a ratio test.
     const int s1 = prune > 0 && n_chunks / prune > 1 ? n_chunks / prune : 1;
     if (prune && g_score_prune && n_chunks > s1) {
-        score(chunk / 2, 0, 2 * s1, groups, s1 * chunk);
+        score(chunk / 2, 0, 2 * s1, groups, s1 * chunk, false);
         hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, s1 * chunk);
         // the survivors are few: quarter chunks, and a grid an eighth of the list
         // wide and at most 32 chunks deep that strides over whatever is left
         // (measured best among widths 1/2..1/16 and depths 8..32)
         const int rest = (n_chunks - s1) * 4;
-        score(chunk / 4, s1 * 4, rest < 32 ? rest : 32, (groups + 7) / 8, INT_MAX);
+        score(chunk / 4, s1 * 4, rest < 32 ? rest : 32, (groups + 7) / 8, INT_MAX, true);
     } else {
-        score(chunk, 0, n_chunks, groups, INT_MAX);
+        score(chunk, 0, n_chunks, groups, INT_MAX, false);
     }
     return hipGetLastError();
 }
