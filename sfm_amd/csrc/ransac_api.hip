@@ -153,11 +153,18 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, rp.model, 0, nh));
         }
         {
-            // first stage of the scoring: 1/8 of the points when `cap` is the
-            // point count itself (direct call), 1/16 when it is the query count of
-            // a pair, of which the ratio test leaves less than half
+            // First stage of the scoring: it has to outnumber the outliers for the
+            // bound to drop anything.  Sized from the outliers the previous call on
+            // this context ended with (consecutive pairs of one sequence are alike)
+            // plus 30 %; without history, 1/8 of the points when `cap` is the point
+            // count itself (direct call), 1/16 when it is the query count of a pair,
+            // of which the ratio test leaves less than half.  Only the cost depends
+            // on the guess, never the result.
+            int stage1 = std::max(512, cap / (need_results ? 8 : 16));
+            if (ctx->hint_outliers >= 0.0) stage1 = std::max(512, (int)(1.3 * ctx->hint_outliers) + 1);
+            stage1 = std::min(stage1, std::max(512, cap / 2));
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh, need_results ? 8 : 16));
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh, stage1));
         }
         {
             ProfScope ps(ctx, "ransac_select");
@@ -371,6 +378,7 @@ int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int
     if (iters_used) *iters_used = results[R_ITERS];
     if (results[R_OK]) {
         if (n_inliers) *n_inliers = results[R_NINL];
+        ctx->hint_outliers = n - results[R_NINL];
         SFM_HIP(ctx, hipMemcpyAsync(mask, probs[0].mask, n, hipMemcpyDeviceToHost, ctx->stream));
         SFM_HIP(ctx, hipMemcpyAsync(model_out, probs[0].model_out, 72, hipMemcpyDeviceToHost, ctx->stream));
         SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -544,14 +552,21 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
         SFM_HIP(ctx, hipMemcpyAsync(ctx->pin_a.p, ctx->mp_ngood.p, 8 * (size_t)g, hipMemcpyDeviceToHost, s));
         SFM_HIP(ctx, hipStreamSynchronize(s));
         std::memcpy(ng.data(), ctx->pin_a.p, 8 * (size_t)g);
+        double out_sum = 0.0;
+        int out_cnt = 0;
         for (int i = 0; i < g; ++i) {
             n_good[g0 + i] = ng[2 * i];
             n_inliers[g0 + i] = ng[2 * i + 1];
+            if (ng[2 * i + 1] > 0) {
+                out_sum += ng[2 * i] - ng[2 * i + 1];
+                ++out_cnt;
+            }
             if (inlier_matches && ng[2 * i + 1] > 0)
                 SFM_HIP(ctx, hipMemcpyAsync(inlier_matches + (size_t)(g0 + i) * match_capacity,
                                             pds[i].inliers, (size_t)ng[2 * i + 1] * sizeof(sfm_gpu_dmatch),
                                             hipMemcpyDeviceToHost, s));
         }
+        if (out_cnt > 0) ctx->hint_outliers = out_sum / out_cnt;  // sizes the next call's first scoring stage
         SFM_HIP(ctx, hipStreamSynchronize(s));
     }
     return SFM_GPU_OK;

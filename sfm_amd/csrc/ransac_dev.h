@@ -55,10 +55,10 @@ hipError_t launch_ransac_prep(hipStream_t s, const RansacProb* probs, int n_prob
 hipError_t launch_ransac_table(hipStream_t s, const RansacProb* probs, int n_prob, int row0, int nrows);
 hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int n_prob, int nrows);
 hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp);
-// prune > 0: every model is first scored on 1/prune of the point capacity,
-// then the models that provably cannot reach the best count are dropped (their
-// counts stay partial) and the rest go on; the selected model, its count and
-// the mask are the same as with prune = 0.
+// prune > 0: every model is first scored on the first `prune` points, then the
+// models that provably cannot reach the best count are dropped (their counts
+// stay partial) and the rest go on; the selected model, its count and the mask
+// are the same as with prune = 0.
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
                                int n_hyp, int prune);
 void set_ransac_score_filter(int on);

@@ -1880,12 +1880,13 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
         }
     };
     // Two stages with a pruning step between them: every model on the first
-    // 1/prune of the capacity (in half chunks: a single round of workgroups
-    // balances better when they are short), the survivors on the rest.  The
-    // bound only bites when the sample is larger than the outlier share of the
-    // points, the normal case behind a ratio test.
-    const int s1 = prune > 0 && n_chunks / prune > 1 ? n_chunks / prune : 1;
-    if (prune && g_score_prune && n_chunks > s1) {
+    // `prune` points (in half chunks: a single round of workgroups balances
+    // better when they are short), the survivors on the rest.  The bound only
+    // bites when that sample outnumbers the outliers among the points; the
+    // caller sizes it from what it knows about them.
+    // `prune` = points of the first stage, rounded up to whole chunks
+    const int s1 = prune > chunk ? (prune + chunk - 1) / chunk : 1;
+    if (prune > 0 && g_score_prune && n_chunks > s1) {
         score(chunk / 2, 0, 2 * s1, groups, s1 * chunk, false);
         hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, s1 * chunk);
         // the survivors are few: quarter chunks, and a grid an eighth of the list

@@ -134,6 +134,8 @@ struct sfm_gpu_ctx {
     // recover_pose workspaces
     sfm::DevBuf pose_in, pose_out;
     int32_t dbg_pose_votes[4] = {0, 0, 0, 0};
+    // outliers (points - inliers) per problem at the end of the last RANSAC call, -1: none yet
+    double hint_outliers = -1.0;
 
     // device pointers of the last sfm_gpu_ransac call, for the test hooks
     const int32_t* dbg_table = nullptr;
