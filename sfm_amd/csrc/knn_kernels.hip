@@ -774,9 +774,10 @@ __device__ __forceinline__ void insert3(u64& a1, u64& a2, u64& a3, u64 v)
 //           group rows = 32*tile + 8g + 4h + i            (g, i = 0..3)
 //   GM = 1  16x16 tiles: unit = block of 64 rows, sub = quarter (2 bits),
 //           group rows = 64*block + 16j + 4*quarter + i   (j, i = 0..3)
+constexpr int RESCAN_QPW = 32;  // queries per workgroup
 template <int GM>
 __global__ void __launch_bounds__(256)
-knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblocks, int map_mode)
+knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblocks, int map_mode, double skip_r2)
 {
     constexpr int SB = GM ? 2 : 1;           // bits of the sub-unit index
     constexpr int UROWS = GM ? 64 : 32;      // rows per unit
@@ -785,42 +786,79 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
     // train rows then hit a single L2
     const WgCoord wg = decode_wg(blockIdx.x, (uint32_t)qblocks, 1u, map_mode);
     const KnnJob job = jobs[wg.job];
-    const int q = wg.qblock * 8 + (threadIdx.x >> 5);
-    const int l = threadIdx.x & 31;
-    if (q >= job.n_query) return;  // whole 32-lane group leaves together
     const u64 NONE = ~0ull;
     const uint32_t tmask = (1u << TILE_BITS) - 1u;
-    u64 c1 = NONE, c2 = NONE, c3 = NONE;
-    // key = x << 32 | (unit << SB | sub): ascending (x, unit, sub)
-    auto key_of = [&](uint32_t p, uint32_t t0, uint32_t sub) -> u64 {
-        return ((u64)(p >> TILE_BITS) << 32) | (((t0 + (p & tmask)) << SB) | sub);
-    };
-    auto take = [&](const uint4 r) {
-        const uint32_t t0 = r.w & 0x0FFFFFFFu;
-        if (r.x != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.x, t0, (r.w >> 28) & 3u));
-        if (r.y != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.y, t0, (r.w >> 30) & 3u));
-        if (r.z != 0xFFFFFFFFu) insert3(c1, c2, c3, ((u64)(r.z >> TILE_BITS) << 32) | 0xFFFFFFFFu);
-    };
-    if (n_splits == 1) {
-        // a single record is already in ascending (x, unit, sub) order
-        const uint4 r = job.partial[q];
-        const uint32_t t0 = r.w & 0x0FFFFFFFu;
-        if (r.x != 0xFFFFFFFFu) c1 = key_of(r.x, t0, (r.w >> 28) & 3u);
-        if (r.y != 0xFFFFFFFFu) c2 = key_of(r.y, t0, (r.w >> 30) & 3u);
-        if (r.z != 0xFFFFFFFFu) c3 = ((u64)(r.z >> TILE_BITS) << 32) | 0xFFFFFFFFu;
-    } else {
-        for (int j = l; j < n_splits; j += 32) take(job.partial[(size_t)j * job.q_rows_alloc + q]);
-        for (int off = 1; off < 32 && off < n_splits; off <<= 1) {
+    // Step 1, eight threads per query of the workgroup's 32: merge the query's
+    // records (one per split) into the two best groups and the third minimum,
+    // decide whether the query needs neighbours at all, and list those that do.
+    __shared__ u64 s_c[RESCAN_QPW][3];
+    __shared__ int s_list[RESCAN_QPW];
+    __shared__ int s_wcount[4];
+    {
+        const int qi = threadIdx.x >> 3, part = threadIdx.x & 7;
+        const int q = wg.qblock * RESCAN_QPW + qi;
+        bool need = false;
+        u64 c1 = NONE, c2 = NONE, c3 = NONE;
+        if (q < job.n_query) {
+            // key = x << 32 | (unit << SB | sub): ascending (x, unit, sub)
+            auto key_of = [&](uint32_t p, uint32_t t0, uint32_t sub) -> u64 {
+                return ((u64)(p >> TILE_BITS) << 32) | (((t0 + (p & tmask)) << SB) | sub);
+            };
+            for (int j = part; j < n_splits; j += 8) {
+                const uint4 r = job.partial[(size_t)j * job.q_rows_alloc + q];
+                const uint32_t t0 = r.w & 0x0FFFFFFFu;
+                if (r.x != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.x, t0, (r.w >> 28) & 3u));
+                if (r.y != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.y, t0, (r.w >> 30) & 3u));
+                if (r.z != 0xFFFFFFFFu) insert3(c1, c2, c3, ((u64)(r.z >> TILE_BITS) << 32) | 0xFFFFFFFFu);
+            }
+        }
+        for (int off = 1; off < 8 && off < n_splits; off <<= 1) {
             const u64 b1 = __shfl_xor(c1, off), b2 = __shfl_xor(c2, off), b3 = __shfl_xor(c3, off);
             insert3(c1, c2, c3, b1);
             insert3(c1, c2, c3, b2);
             insert3(c1, c2, c3, b3);
         }
-        // lanes 0 .. pow2(n_splits)-1 agree; spread lane 0's result
-        c1 = __shfl(c1, 0, 32);
-        c2 = __shfl(c2, 0, 32);
-        c3 = __shfl(c3, 0, 32);
+        if (part == 0 && q < job.n_query) {
+            need = true;
+            // Pipelines that only keep the queries passing the ratio test
+            // d1 < r * d2 (skip_r2 = r^2 > 0) need no neighbours for a query that
+            // certainly fails it.  The best group's minimum bounds the nearest
+            // distance from below, D1 >= qn + 2 x1 - 2 KEY, and the second group's
+            // minimum belongs to another row, so the second nearest distance is at
+            // most U = qn + 2 x2 - 2 KEY + 1: when D1 >= r^2 U, with a margin far
+            // wider than the float rounding of the two square roots, the test fails
+            // whatever the exact neighbours are.  Such a query reports none.
+            if (skip_r2 > 0.0 && c2 != NONE) {
+                const double qn0 = (double)job.q_qn[q] - 2.0 * (double)KEY_OFFSET;
+                const double d1_lo = qn0 + 2.0 * (double)(uint32_t)(c1 >> 32);
+                const double d2_hi = qn0 + 2.0 * (double)(uint32_t)(c2 >> 32) + 1.0;
+                if (d1_lo >= skip_r2 * d2_hi * (1.0 + 1e-6) + 2.0) {
+                    need = false;
+                    job.counts[q] = 0;
+                }
+            }
+            s_c[qi][0] = c1;
+            s_c[qi][1] = c2;
+            s_c[qi][2] = c3;
+        }
+        // list in ascending query order: per wavefront (8 queries), then across the 4
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) s_wcount[wv] = __popcll(m);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wv; ++w) base += s_wcount[w];
+        if (need) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = qi;
     }
+    __syncthreads();
+    const int s_count = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+    const int n_need = s_count;
+    const int l = threadIdx.x & 31;
+    // Step 2: the eight 32-lane groups take the listed queries in turn.
+    for (int it = threadIdx.x >> 5; it < n_need; it += 8) {
+    const int qi = s_list[it];
+    const int q = wg.qblock * RESCAN_QPW + qi;
+    const u64 c1 = s_c[qi][0], c2 = s_c[qi][1], c3 = s_c[qi][2];
     const uint32_t third_x = (uint32_t)(c3 >> 32);  // 0xFFFFFFFF when there is no third group
     // c1 < c2 compares (x, unit, sub).  For the lane order to be the row order
     // the group with the smaller (unit, sub) must come first.
@@ -925,16 +963,18 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
         }
         job.out[(size_t)q * k + l] = m;
     }
-    if (l != 0) return;
-    job.counts[q] = (e1 != 0xFFFFFFFFu ? 1 : 0) + ((k > 1 && e2 != 0xFFFFFFFFu) ? 1 : 0);
-    if (e2 != 0xFFFFFFFFu) {
-        const int32_t d2 = (int32_t)(e2 >> 5);
-        const uint32_t x2 = (uint32_t)(d2 - qn + 2 * KEY_OFFSET) >> 1;
-        if (d2 >= (1 << 22) || third_x <= x2) {
-            const int slot = atomicAdd(job.redo, 1);
-            job.redo[1 + slot] = q;
+    if (l == 0) {
+        job.counts[q] = (e1 != 0xFFFFFFFFu ? 1 : 0) + ((k > 1 && e2 != 0xFFFFFFFFu) ? 1 : 0);
+        if (e2 != 0xFFFFFFFFu) {
+            const int32_t d2 = (int32_t)(e2 >> 5);
+            const uint32_t x2 = (uint32_t)(d2 - qn + 2 * KEY_OFFSET) >> 1;
+            if (d2 >= (1 << 22) || third_x <= x2) {
+                const int slot = atomicAdd(job.redo, 1);
+                job.redo[1 + slot] = q;
+            }
         }
     }
+    }  // listed queries
 }
 
 // Float-ranked exhaustive pass for the queries flagged above: ranks train rows
@@ -1206,19 +1246,20 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
 }
 
 hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_query_max,
-                               int n_splits, int k, int group_mode)
+                               int n_splits, int k, int group_mode, double skip_ratio)
 {
-    const int qblocks = (n_query_max + 7) / 8;
+    const double skip_r2 = skip_ratio > 0.0 && k == 2 ? skip_ratio * skip_ratio : 0.0;
+    const int qblocks = (n_query_max + RESCAN_QPW - 1) / RESCAN_QPW;
     if (qblocks <= 0 || n_jobs <= 0) return hipSuccess;
     const long long total = (long long)qblocks * n_jobs;
     if (total > 0x7FFFFFFFll) return hipErrorInvalidValue;
     const int mode = n_jobs % 8 == 0 ? 1 : 0;
     if (group_mode)
         hipLaunchKernelGGL(knn_rescan_kernel<1>, dim3((unsigned)total), dim3(256), 0, s, jobs_dev, n_splits, k,
-                           qblocks, mode);
+                           qblocks, mode, skip_r2);
     else
         hipLaunchKernelGGL(knn_rescan_kernel<0>, dim3((unsigned)total), dim3(256), 0, s, jobs_dev, n_splits, k,
-                           qblocks, mode);
+                           qblocks, mode, skip_r2);
     return hipGetLastError();
 }
 

@@ -532,7 +532,9 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
         }
         {
             ProfScope ps(ctx, "knn_finalize");
-            SFM_HIP(ctx, launch_knn_finalize(s, djobs, g, nq_max, plan.n_splits, 2, plan.group_mode));
+            // the pair loop keeps only the ratio-test survivors: queries that
+            // certainly fail the test are not given exact neighbours
+            SFM_HIP(ctx, launch_knn_finalize(s, djobs, g, nq_max, plan.n_splits, 2, plan.group_mode, params->ratio));
         }
         {
             ProfScope ps(ctx, "knn_redo");

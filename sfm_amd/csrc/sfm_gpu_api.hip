@@ -126,7 +126,7 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
     }
     {
         ProfScope ps(ctx, "knn_finalize");
-        SFM_HIP(ctx, launch_knn_finalize(ctx->stream, ctx->jobs.as<KnnJob>(), 1, nq, plan.n_splits, k, plan.group_mode));
+        SFM_HIP(ctx, launch_knn_finalize(ctx->stream, ctx->jobs.as<KnnJob>(), 1, nq, plan.n_splits, k, plan.group_mode, 0.0));
     }
     {
         ProfScope ps(ctx, "knn_redo");
