@@ -171,3 +171,38 @@ def test_match_pairs_many_small_pairs_in_two_groups_and_bad_index(gpu_ctx):
     assert e.value.code == _lib.ERR_ARG
     for im in images:
         im.close()
+
+
+@pytest.mark.parametrize("ratio", [0.3, 0.6, 0.8, 0.95, 0.999, 1.0, 1.5])
+def test_ratio_screening_never_changes_the_survivors(gpu_ctx, oracle, ratio):
+    """The pair pipeline gives no exact neighbours to queries that certainly fail
+    the ratio test; whatever the ratio, the survivors (and what RANSAC makes of
+    them) are those of the oracle's knnMatch + ratio test on every query.  The
+    descriptor noise is spread so that d1/d2 covers the whole range around each
+    tested ratio."""
+    n = 3000
+    rng = np.random.default_rng(int(ratio * 1000))
+    Q = synth.sift_like(n, 311)
+    T = synth.sift_like(n, 312)
+    rows_q = rng.permutation(n)[:1500]
+    rows_t = rng.permutation(n)[:1500]
+    sigma = rng.uniform(2.0, 40.0, (1500, 1))          # from sure matches to indistinguishable ones
+    T[rows_t] = np.clip(Q[rows_q] + np.rint(rng.normal(0, 1, (1500, 128)) * sigma), 0, 255).astype(np.float32)
+    T[5] = T[6]                                          # exact duplicates: d1 == d2 for their match
+    planted = np.full(n, -1, np.int64)
+    planted[rows_q] = rows_t
+    kq, kt = synth.keypoints_for_pair(n, n, planted, 313)
+    imgs = [matcher.Image(gpu_ctx, Q, kq), matcher.Image(gpu_ctx, T, kt)]
+    pairs = np.array([[0, 1], [1, 0]], np.int32)
+    n_good, n_inl, sel = matcher.match_pairs(gpu_ctx, imgs, pairs, None, ratio=ratio, model=matcher.MODEL_FUNDAMENTAL,
+                                             mode=matcher.RANSAC_FIXED, n_hyp=64, prob=0.99, threshold=3.0,
+                                             want_matches=True)
+    for p, (dq, dt, k1, k2) in enumerate([(Q, T, kq, kt), (T, Q, kt, kq)]):
+        ng, osel = _oracle_pair(oracle, dq, dt, k1, k2, None, ratio, 1, prob=0.99, threshold=3.0, fixed_count=64)
+        assert n_good[p] == ng and n_inl[p] == len(osel)
+        assert (sel[p]["queryIdx"] == osel["queryIdx"]).all() and (sel[p]["trainIdx"] == osel["trainIdx"]).all()
+        assert (sel[p]["distance"].view(np.uint32) == osel["distance"].view(np.uint32)).all()
+    if ratio <= 0.95:
+        assert 0 < n_good[0] < n
+    for im in imgs:
+        im.close()
