@@ -188,13 +188,11 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
     };
     std::vector<St> st(n_prob);
     const int max_it = std::max(rp.max_iters, 1);
-    int rc = fetch_results();
-    if (rc) return rc;
-    for (int p = 0; p < n_prob; ++p) {
-        st[p].n = results[(size_t)p * R_COUNT + R_N];
-        st[p].niters = max_it;
-        if (st[p].n < m) { st[p].done = true; st[p].failed = true; }
-    }
+    int rc = 0;
+    // The point counts are only known on the device; they come back with the
+    // first batch's counts (the kernels themselves leave problems with n < m
+    // alone), which saves one round trip per call.
+    for (int p = 0; p < n_prob; ++p) st[p].niters = max_it;
     std::vector<int32_t> counts;
     int done_rows = 0;
     while (done_rows < max_it) {
@@ -240,6 +238,11 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         rc = fetch_results();
         if (rc) return rc;
         std::memcpy(counts.data(), counts_pin, counts.size() * 4);
+        if (done_rows == 0)
+            for (int p = 0; p < n_prob; ++p) {
+                st[p].n = results[(size_t)p * R_COUNT + R_N];
+                if (st[p].n < m) { st[p].done = true; st[p].failed = true; }
+            }
         for (int p = 0; p < n_prob; ++p) {
             St& t = st[p];
             if (t.done) continue;
