@@ -167,12 +167,9 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh, stage1));
         }
         {
+            // winner, then its mask and model copy, by the same workgroup per problem
             ProfScope ps(ctx, "ransac_select");
             SFM_HIP(ctx, launch_ransac_select(s, dprobs, n_prob, nh));
-        }
-        {
-            ProfScope ps(ctx, "ransac_mask");
-            SFM_HIP(ctx, launch_ransac_mask(s, dprobs, n_prob, cap));
         }
         // the whole fixed-count path runs without the host; callers that keep
         // working on the device need not wait here

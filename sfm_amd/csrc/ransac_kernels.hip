@@ -1741,9 +1741,12 @@ __global__ void __launch_bounds__(1024) ransac_prune_kernel(const RansacProb* __
 // Fixed-count winner: the first (hypothesis, model) in scan order whose count is
 // the maximum, provided it reaches m — what the sequential loop
 // `if (good > max(best, m-1))` ends with.
+// The same workgroup then writes the winner's inlier mask and a copy of the
+// model (what ransac_mask_kernel does for the adaptive mode).
 __global__ void __launch_bounds__(1024) ransac_select_kernel(const RansacProb* __restrict__ probs, int n_hyp)
 {
     __shared__ unsigned long long sh[16];
+    __shared__ int s_sel[4];  // ok, hypothesis, model, direct
     const RansacProb pb = probs[blockIdx.x];
     const int n = *pb.n_ptr;
     const int tid = threadIdx.x;
@@ -1767,21 +1770,51 @@ __global__ void __launch_bounds__(1024) ransac_select_kernel(const RansacProb* _
     if (tid == 0) {
         for (int i = 1; i < 16; ++i) best = sh[i] > best ? sh[i] : best;
         pb.result[R_ITERS] = valid;
-        if (pb.result[R_DIRECT]) {
-            const int ok = pb.nmodels[0] > 0;
+        int ok = 0, hyp = 0, q = 0;
+        const int direct = pb.result[R_DIRECT];
+        if (direct) {
+            ok = pb.nmodels[0] > 0;
             pb.result[R_OK] = ok;
             pb.result[R_HYP] = 0;
             pb.result[R_Q] = 0;
             pb.result[R_NINL] = ok ? n : 0;
         } else if (best != 0) {
             const unsigned e = 0xFFFFFFFFu - (unsigned)best;
+            ok = 1;
+            hyp = (int)(e / 10);
+            q = (int)(e % 10);
             pb.result[R_OK] = 1;
-            pb.result[R_HYP] = (int)(e / 10);
-            pb.result[R_Q] = (int)(e % 10);
+            pb.result[R_HYP] = hyp;
+            pb.result[R_Q] = q;
             pb.result[R_NINL] = (int)(best >> 32);
         } else {
             pb.result[R_OK] = 0;
         }
+        s_sel[0] = ok;
+        s_sel[1] = hyp;
+        s_sel[2] = q;
+        s_sel[3] = direct;
+    }
+    __syncthreads();
+    if (!s_sel[0]) return;  // mask left untouched when no model was found
+    const double* Mg = pb.models + (size_t)s_sel[1] * 90 + s_sel[2] * 9;
+    double M[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M[i] = Mg[i];
+    if (tid < 9) pb.model_out[tid] = M[tid];
+    const bool direct = s_sel[3] != 0;
+    for (int i = tid; i < n; i += 1024) {
+        int f;
+        if (direct) {
+            f = 1;
+        } else if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
+            f = sampson_inlier(M, pb.x1[2 * i], pb.x1[2 * i + 1], pb.x2[2 * i], pb.x2[2 * i + 1], pb.tf, pb.tlo,
+                               pb.thi);
+        } else {
+            f = symepi_inlier(M, pb.f1[2 * i], pb.f1[2 * i + 1], pb.f2[2 * i], pb.f2[2 * i + 1], pb.tf, pb.tlo,
+                              pb.thi);
+        }
+        pb.mask[i] = (uint8_t)f;
     }
 }
 
