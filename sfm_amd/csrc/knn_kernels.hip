@@ -968,7 +968,25 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
         if (e2 != 0xFFFFFFFFu) {
             const int32_t d2 = (int32_t)(e2 >> 5);
             const uint32_t x2 = (uint32_t)(d2 - qn + 2 * KEY_OFFSET) >> 1;
-            if (d2 >= (1 << 22) || third_x <= x2) {
+            bool redo = d2 >= (1 << 22) || third_x <= x2;
+            if (redo && skip_r2 > 0.0 && d2 < (1 << 22)) {
+                // A row outside the two groups may be the true second neighbour:
+                // its squared distance is at least L3 = qn + 2 third - 2 KEY and
+                // the true second distance lies in [L3, d2].  The pair pipeline
+                // only keeps (best match, ratio verdict): when the best match is
+                // strictly nearer than L3 and the verdict is the same at both ends
+                // of that range (margins as in the screening above), the exhaustive
+                // pass has nothing to add.
+                const double d1 = (double)(e1 >> 5);
+                const double l3 = (double)qn - 2.0 * (double)KEY_OFFSET + 2.0 * (double)third_x;
+                if (d1 < l3 && (d1 + 2.0) * (1.0 + 1e-6) < skip_r2 * l3) {
+                    redo = false;  // passes whatever the second neighbour is; the record of the best is exact
+                } else if (d1 >= skip_r2 * (double)d2 * (1.0 + 1e-6) + 2.0) {
+                    redo = false;  // fails even against the farthest candidate
+                    job.counts[q] = 0;
+                }
+            }
+            if (redo) {
                 const int slot = atomicAdd(job.redo, 1);
                 job.redo[1 + slot] = q;
             }

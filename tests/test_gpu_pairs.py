@@ -206,3 +206,37 @@ def test_ratio_screening_never_changes_the_survivors(gpu_ctx, oracle, ratio):
         assert 0 < n_good[0] < n
     for im in imgs:
         im.close()
+
+
+@pytest.mark.parametrize("ratio", [0.5, 0.8, 1.0])
+def test_pipeline_on_tie_heavy_descriptors(gpu_ctx, oracle, ratio):
+    """Low-entropy descriptors: many equal distances, many group-minimum ties.
+    The pipeline resolves a tie without the exhaustive pass only when neither
+    the best match nor the ratio verdict can depend on it; the survivors are
+    still exactly the oracle's."""
+    n = 1500
+    rng = np.random.default_rng(7 + int(ratio * 10))
+    Q = (rng.integers(0, 3, (n, 128)) * 40).astype(np.float32)
+    T = (rng.integers(0, 3, (n, 128)) * 40).astype(np.float32)
+    rows = rng.permutation(n)[:700]
+    T[rows] = Q[rng.permutation(n)[:700]]            # exact copies, some of them repeated
+    T[rows[:50]] = T[rows[50:100]]
+    flip = rng.integers(0, 128, 700)
+    T[rows, flip] = 80.0 - T[rows, flip]              # one coordinate off for most copies
+    kq = np.stack([rng.uniform(0, synth.IMG_W, n), rng.uniform(0, synth.IMG_H, n)], 1).astype(np.float32)
+    kt = np.stack([rng.uniform(0, synth.IMG_W, n), rng.uniform(0, synth.IMG_H, n)], 1).astype(np.float32)
+    imgs = [matcher.Image(gpu_ctx, Q, kq), matcher.Image(gpu_ctx, T, kt)]
+    pairs = np.array([[0, 1], [1, 0]], np.int32)
+    n_good, n_inl, sel = matcher.match_pairs(gpu_ctx, imgs, pairs, None, ratio=ratio, model=matcher.MODEL_FUNDAMENTAL,
+                                             mode=matcher.RANSAC_FIXED, n_hyp=32, prob=0.99, threshold=1e6,
+                                             want_matches=True)
+    for p, (dq, dt) in enumerate([(Q, T), (T, Q)]):
+        m, c = oracle.knn_match(dq, dt, 2, nthreads=4)
+        good = m[oracle.ratio_test(m, c, ratio), 0]
+        assert n_good[p] == len(good)
+        if n_inl[p] == len(good):                      # threshold 1e6: every survivor is an inlier
+            assert (sel[p]["queryIdx"] == good["queryIdx"]).all() and (sel[p]["trainIdx"] == good["trainIdx"]).all()
+            assert (sel[p]["distance"].view(np.uint32) == good["distance"].view(np.uint32)).all()
+    assert n_good[0] > 50
+    for im in imgs:
+        im.close()
