@@ -139,14 +139,25 @@ __device__ bool null_space_9(SolveWs& w, int rows, int lane)
     if (lane < 9) w.perm[lane] = lane;
     __syncthreads();
     for (int p = 0; p < rows; ++p) {
-        int bi = p, bj = p;
+        // pivot = first maximum of |A[i][j]|, i >= p, j >= p, in row-major scan:
+        // one element per lane, then a butterfly on (larger value, smaller index)
         double best = -1.0;
-        for (int i = p; i < rows; ++i)
-            for (int j = p; j < 9; ++j) {
-                const double v = fabs(A[i * 9 + j]);
-                if (v > best) { best = v; bi = i; bj = j; }
+        int bidx = 0x7FFFFFFF;
+        if (lane < rows * 9) {
+            const int i = lane / 9, j = lane % 9;
+            if (i >= p && j >= p) {
+                best = fabs(A[lane]);
+                bidx = lane;
             }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bidx, off);
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
         if (!(best > 0.0)) return false;
+        const int bi = bidx / 9, bj = bidx % 9;
         __syncthreads();
         if (bi != p && lane < 9) {
             const double t = A[p * 9 + lane];
