@@ -304,32 +304,59 @@ __device__ bool five_point_wave(SolveWs& w, const double* x1s, const double* x2s
     }
     __syncthreads();
 
-    // Gauss-Jordan on the 10 leading columns, partial pivoting (first maximum)
-    for (int p = 0; p < 10; ++p) {
-        int bi = p;
-        double best = -1.0;
-        for (int i = p; i < 10; ++i) {
-            const double v = fabs(w.A[i][p]);
-            if (v > best) { best = v; bi = i; }
+    // Gauss-Jordan on the 10 leading columns, partial pivoting (first maximum),
+    // in registers: lane j < 20 holds column j.  The pivot search is lane p's own
+    // business, everything the other lanes need from it (pivot row number, pivot,
+    // the multipliers A[i][p]) travels by readlane; no LDS, no barrier.  Same
+    // operations on the same values as the row-by-row statement of the oracle.
+    {
+        double a[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) a[i] = lane < 20 ? w.A[i][lane] : 0.0;
+        auto bcast = [](double v, int src) -> double {
+            const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+            const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+            return __hiloint2double(hi, lo);
+        };
+        bool singular = false;
+#pragma unroll
+        for (int p = 0; p < 10; ++p) {
+            int bi = p;
+            double best = -1.0;
+#pragma unroll
+            for (int i = p; i < 10; ++i) {
+                const double v = fabs(a[i]);
+                if (v > best) { best = v; bi = i; }
+            }
+            bi = __builtin_amdgcn_readlane(bi, p);
+            best = bcast(best, p);
+            if (!(best > 0.0)) { singular = true; break; }
+#pragma unroll
+            for (int i = p + 1; i < 10; ++i)
+                if (bi == i) {  // uniform
+                    const double t = a[p];
+                    a[p] = a[i];
+                    a[i] = t;
+                }
+            const double piv = bcast(a[p], p);
+            if (lane > p) a[p] = a[p] / piv;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                if (i == p) continue;
+                const double f = bcast(a[i], p);
+                if (lane > p) a[i] = a[i] - f * a[p];
+            }
+            if (lane == p) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) a[i] = (i == p) ? 1.0 : 0.0;
+            }
         }
-        if (!(best > 0.0)) return false;
-        __syncthreads();
-        if (bi != p && lane < 20) {
-            const double t = w.A[p][lane];
-            w.A[p][lane] = w.A[bi][lane];
-            w.A[bi][lane] = t;
+        if (singular) return false;
+        // rows 4..9 of the trailing columns are all that is read from here on
+        if (lane >= 10 && lane < 20) {
+#pragma unroll
+            for (int i = 4; i < 10; ++i) w.A[i][lane] = a[i];
         }
-        __syncthreads();
-        const double piv = w.A[p][p];
-        __syncthreads();
-        if (lane > p && lane < 20) w.A[p][lane] = w.A[p][lane] / piv;
-        __syncthreads();
-        for (int o = lane; o < 200; o += 64) {
-            const int i = o / 20, j = o % 20;
-            if (i != p && j > p) w.A[i][j] = w.A[i][j] - w.A[i][p] * w.A[p][j];
-        }
-        __syncthreads();
-        if (lane < 10) w.A[lane][p] = (lane == p) ? 1.0 : 0.0;
         __syncthreads();
     }
 
