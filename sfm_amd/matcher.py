@@ -335,6 +335,24 @@ def prepare_many(ctx, desc_ptrs, ns, step, dtype, kp_ptrs, packed_ptrs):
     ctx.check(ctx._L.sfm_gpu_image_prepare_many(ctx.handle, d, ptr(n), step, 128, dtype, k, p, cnt))
 
 
+class PrepareBatch:
+    """prepare_many with its argument arrays built once: a caller that converts
+    the same device buffers again and again (a pipeline loop) then pays one
+    foreign call per step instead of re-marshalling hundreds of pointers."""
+
+    def __init__(self, ctx, desc_ptrs, ns, step, dtype, kp_ptrs, packed_ptrs):
+        self.ctx = ctx
+        cnt = len(ns)
+        self._d = (ctypes.c_void_p * cnt)(*desc_ptrs)
+        self._p = (ctypes.c_void_p * cnt)(*packed_ptrs)
+        self._k = (ctypes.c_void_p * cnt)(*kp_ptrs) if kp_ptrs is not None else None
+        self._n = np.ascontiguousarray(ns, dtype=np.int32)
+        self._args = (ctx.handle, self._d, ptr(self._n), step, 128, dtype, self._k, self._p, cnt)
+
+    def run(self):
+        self.ctx.check(self.ctx._L.sfm_gpu_image_prepare_many(*self._args))
+
+
 def check_inputs(ctx):
     """Waits for the stream and raises if a prepared image held non-u8 values."""
     ctx.check(ctx._L.sfm_gpu_check_inputs(ctx.handle))
