@@ -240,3 +240,44 @@ def test_pipeline_on_tie_heavy_descriptors(gpu_ctx, oracle, ratio):
     assert n_good[0] > 50
     for im in imgs:
         im.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+def test_images_prepared_in_device_memory_match_owned_images(gpu_ctx, dtype):
+    """Descriptors that already sit in device memory (float rows as
+    detectAndCompute leaves them, main.cpp:178, or bytes) converted by one
+    batched call into caller-owned blocks: same pipeline results as images the
+    library copied from the host, and the conversion can be repeated."""
+    import torch
+    n, n_img = 1300, 4
+    rng = np.random.default_rng(77)
+    pool = synth.sift_like(2000, 78)
+    descs = [np.clip(pool[rng.permutation(2000)[:n]] + rng.integers(-4, 5, (n, 128)), 0, 255).astype(np.float32)
+             for _ in range(n_img)]
+    kps = [np.stack([rng.uniform(0, synth.IMG_W, n), rng.uniform(0, synth.IMG_H, n)], 1).astype(np.float32)
+           for _ in range(n_img)]
+    pairs = np.array([[0, 1], [1, 2], [2, 3], [3, 0]], np.int32)
+    kw = dict(ratio=0.8, model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED, prob=0.99,
+              threshold=3.0, n_hyp=64)
+    owned = [matcher.Image(gpu_ctx, d, k) for d, k in zip(descs, kps)]
+    g0, i0, s0 = matcher.match_pairs(gpu_ctx, owned, pairs, None, want_matches=True, **kw)
+
+    d_desc = torch.from_numpy(np.stack(descs).astype(dtype)).cuda()
+    d_kp = torch.from_numpy(np.stack(kps)).cuda()
+    d_packed = torch.zeros((n_img, matcher.image_packed_bytes(n)), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    prep = matcher.PrepareBatch(gpu_ctx, [d_desc[i].data_ptr() for i in range(n_img)], [n] * n_img,
+                                128 * np.dtype(dtype).itemsize,
+                                matcher.DESC_U8 if dtype == np.uint8 else matcher.DESC_F32,
+                                [d_kp[i].data_ptr() for i in range(n_img)],
+                                [d_packed[i].data_ptr() for i in range(n_img)])
+    wrapped = [matcher.WrappedImage(gpu_ctx, d_packed[i].data_ptr(), n) for i in range(n_img)]
+    for _ in range(2):
+        prep.run()
+        g1, i1, s1 = matcher.match_pairs(gpu_ctx, wrapped, pairs, None, want_matches=True, **kw)
+        matcher.check_inputs(gpu_ctx)
+        assert (g1 == g0).all() and (i1 == i0).all() and g0.sum() > 0
+        for a, b in zip(s0, s1):
+            assert (a == b).all()
+    for im in owned + wrapped:
+        im.close()
