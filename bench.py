@@ -70,8 +70,8 @@ def cpu_baseline(descs, kps, n_hyp, threads, n_pairs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs-per-step", type=int, default=64)
     ap.add_argument("--n-desc", type=int, default=8192)
     ap.add_argument("--hyps", type=int, default=2048)

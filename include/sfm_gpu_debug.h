@@ -54,8 +54,9 @@ int sfm_gpu_debug_set_score_filter(int on);
  * between stages, drops the models that provably cannot reach the best count
  * (their entries in the dumped counts stay partial, never above the true
  * count).  0 switches the pruning off so that every dumped count is complete;
- * 1 (default) on.  The selected model, its inlier count and the mask are the
- * same either way.  Process-wide. */
+ * 1 (default) on; 2 on, but never more than one cut (timing comparisons).  The
+ * selected model, its inlier count and the mask are the same either way.
+ * Process-wide. */
 int sfm_gpu_debug_set_score_prune(int on);
 
 /* Vote counts of the four pose candidates in the last sfm_gpu_recover_pose call

@@ -163,8 +163,14 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             int stage1 = std::max(512, cap / (need_results ? 8 : 16));
             if (ctx->hint_outliers >= 0.0) stage1 = std::max(512, (int)(1.3 * ctx->hint_outliers) + 1);
             stage1 = std::min(stage1, std::max(512, cap / 2));
+            // A second cut about a third of the way through the remaining points,
+            // when the previous call says how many points to expect and there are
+            // enough of them left to pay for the extra launches.
+            int mid = 0;
+            const int s1_pts = (stage1 + 127) / 128 * 128;
+            if (ctx->hint_points - s1_pts >= 1024.0) mid = s1_pts + (int)(0.35 * (ctx->hint_points - s1_pts));
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh, stage1));
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh, stage1, mid));
         }
         {
             // winner, then its mask and model copy, by the same workgroup per problem
@@ -209,7 +215,7 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         }
         {
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, done_rows, b, 0));
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, done_rows, b, 0, 0));
         }
         counts.resize((size_t)n_prob * b * 10);
         // the problems' workspaces are carved at a constant stride: one strided copy
@@ -379,6 +385,7 @@ int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int
     if (results[R_OK]) {
         if (n_inliers) *n_inliers = results[R_NINL];
         ctx->hint_outliers = n - results[R_NINL];
+        ctx->hint_points = n;
         SFM_HIP(ctx, hipMemcpyAsync(mask, probs[0].mask, n, hipMemcpyDeviceToHost, ctx->stream));
         SFM_HIP(ctx, hipMemcpyAsync(model_out, probs[0].model_out, 72, hipMemcpyDeviceToHost, ctx->stream));
         SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -554,13 +561,14 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
         SFM_HIP(ctx, hipMemcpyAsync(ctx->pin_a.p, ctx->mp_ngood.p, 8 * (size_t)g, hipMemcpyDeviceToHost, s));
         SFM_HIP(ctx, hipStreamSynchronize(s));
         std::memcpy(ng.data(), ctx->pin_a.p, 8 * (size_t)g);
-        double out_sum = 0.0;
+        double out_sum = 0.0, pts_sum = 0.0;
         int out_cnt = 0;
         for (int i = 0; i < g; ++i) {
             n_good[g0 + i] = ng[2 * i];
             n_inliers[g0 + i] = ng[2 * i + 1];
             if (ng[2 * i + 1] > 0) {
                 out_sum += ng[2 * i] - ng[2 * i + 1];
+                pts_sum += ng[2 * i];
                 ++out_cnt;
             }
             if (inlier_matches && ng[2 * i + 1] > 0)
@@ -568,7 +576,10 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
                                             pds[i].inliers, (size_t)ng[2 * i + 1] * sizeof(sfm_gpu_dmatch),
                                             hipMemcpyDeviceToHost, s));
         }
-        if (out_cnt > 0) ctx->hint_outliers = out_sum / out_cnt;  // sizes the next call's first scoring stage
+        if (out_cnt > 0) {  // sizes the next call's scoring stages
+            ctx->hint_outliers = out_sum / out_cnt;
+            ctx->hint_points = pts_sum / out_cnt;
+        }
         SFM_HIP(ctx, hipStreamSynchronize(s));
     }
     return SFM_GPU_OK;

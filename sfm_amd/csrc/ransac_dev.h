@@ -60,7 +60,7 @@ hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_pro
 // stay partial) and the rest go on; the selected model, its count and the mask
 // are the same as with prune = 0.
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
-                               int n_hyp, int prune);
+                               int n_hyp, int prune, int mid);
 void set_ransac_score_filter(int on);
 void set_ransac_score_prune(int on);
 hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp);

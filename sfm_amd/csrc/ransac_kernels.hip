@@ -1923,7 +1923,7 @@ hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_pro
     return hipGetLastError();
 }
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
-                               int n_hyp, int prune)
+                               int n_hyp, int prune, int mid)
 {
     const int maxm = model == SFM_GPU_MODEL_ESSENTIAL ? 10 : 3;
     hipLaunchKernelGGL(ransac_compact_kernel, dim3(n_prob), dim3(1024), 0, s, probs, hyp0, n_hyp, maxm);
@@ -1950,21 +1950,39 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
                                    chunk_pts, f, chunk0, pts_end);
         }
     };
-    // Two stages with a pruning step between them: every model on the first
+    // Stages with a pruning step between them: every model on the first
     // `prune` points (in half chunks: a single round of workgroups balances
     // better when they are short), the survivors on the rest.  The bound only
     // bites when that sample outnumbers the outliers among the points; the
-    // caller sizes it from what it knows about them.
-    // `prune` = points of the first stage, rounded up to whole chunks
-    const int s1 = prune > chunk ? (prune + chunk - 1) / chunk : 1;
-    if (prune > 0 && g_score_prune && n_chunks > s1) {
-        score(chunk / 2, 0, 2 * s1, groups, s1 * chunk, false);
-        hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, s1 * chunk);
-        // the survivors are few: quarter chunks, and a grid an eighth of the list
-        // wide and at most 32 chunks deep that strides over whatever is left
-        // (measured best among widths 1/2..1/16 and depths 8..32)
-        const int rest = (n_chunks - s1) * 4;
-        score(chunk / 4, s1 * 4, rest < 32 ? rest : 32, (groups + 7) / 8, INT_MAX, true);
+    // caller sizes it from what it knows about them.  The survivors of the
+    // first cut are still of mixed quality (anything above roughly half the
+    // winner's inlier rate), so when the caller also knows about how many
+    // points there are it names a point `mid` inside the rest where the list is
+    // cut again; by then only models close to the winner remain.
+    // `prune` = points of the first stage, rounded up to a multiple of 128 and
+    // split into equal pieces of at most 256
+    const int p1 = (prune + 127) / 128 * 128;
+    const int p_end = n_chunks * chunk;
+    if (prune > 0 && g_score_prune && p_end > p1) {
+        const int ny = (p1 + 255) / 256;
+        score(((p1 + ny - 1) / ny + 3) & ~3, 0, ny, groups, p1, false);
+        hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, p1);
+        // the survivors are few: pieces of 128 points, and a grid an eighth of
+        // the list wide (a sixteenth after the second cut) and at most 32 pieces
+        // deep that strides over whatever is left (measured best among widths
+        // 1/2..1/32, depths 8..64 and pieces of 32..128 points)
+        int pm = (mid + 127) / 128 * 128;
+        if (!(g_score_prune == 1 && pm > p1 && pm < p_end)) pm = 0;
+        if (pm) {
+            const int c = (pm - p1) / 128;
+            score(128, p1 / 128, c < 32 ? c : 32, (groups + 7) / 8, pm, true);
+            hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, pm);
+            const int c2 = (p_end - pm) / 128;
+            score(128, pm / 128, c2 < 32 ? c2 : 32, (groups + 15) / 16, INT_MAX, true);
+        } else {
+            const int c = (p_end - p1) / 128;
+            score(128, p1 / 128, c < 32 ? c : 32, (groups + 7) / 8, INT_MAX, true);
+        }
     } else {
         score(chunk, 0, n_chunks, groups, INT_MAX, false);
     }

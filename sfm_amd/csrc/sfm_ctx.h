@@ -136,6 +136,7 @@ struct sfm_gpu_ctx {
     int32_t dbg_pose_votes[4] = {0, 0, 0, 0};
     // outliers (points - inliers) per problem at the end of the last RANSAC call, -1: none yet
     double hint_outliers = -1.0;
+    double hint_points = -1.0;  // correspondences per problem in the previous call (as hint_outliers)
 
     // device pointers of the last sfm_gpu_ransac call, for the test hooks
     const int32_t* dbg_table = nullptr;
