@@ -777,8 +777,9 @@ __device__ __forceinline__ void insert3(u64& a1, u64& a2, u64& a3, u64 v)
 constexpr int RESCAN_QPW = 32;  // queries per workgroup
 template <int GM>
 __global__ void __launch_bounds__(256)
-knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblocks, int map_mode, double skip_r2)
+knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblocks, int map_mode, double ratio)
 {
+    const double skip_r2 = ratio * ratio;  // 0 when the caller wants every neighbour
     constexpr int SB = GM ? 2 : 1;           // bits of the sub-unit index
     constexpr int UROWS = GM ? 64 : 32;      // rows per unit
     constexpr int JSTRIDE = GM ? 16 : 8;     // row stride between the four runs of a group
@@ -949,14 +950,16 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
     const int row1 = row_of((int)(e1 & 31u));
     const int row2 = row_of((int)(e2 & 31u));
     // lane j < k writes neighbour j
+    const uint32_t ej = l == 0 ? e1 : e2;
+    const float dist_j = sqrt_d2(ej >> 5);
+    const float dist_second = __shfl(dist_j, 1, 32);  // for lane 0's ratio verdict below
     if (l < k) {
-        const uint32_t ej = l == 0 ? e1 : e2;
         sfm_gpu_dmatch m;
         m.queryIdx = q;
         m.imgIdx = 0;
         if (ej != 0xFFFFFFFFu) {
             m.trainIdx = l == 0 ? row1 : row2;
-            m.distance = sqrt_d2(ej >> 5);
+            m.distance = dist_j;
         } else {
             m.trainIdx = -1;
             m.distance = __uint_as_float(0x7f7fffffu);  // FLT_MAX
@@ -964,11 +967,12 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
         job.out[(size_t)q * k + l] = m;
     }
     if (l == 0) {
-        job.counts[q] = (e1 != 0xFFFFFFFFu ? 1 : 0) + ((k > 1 && e2 != 0xFFFFFFFFu) ? 1 : 0);
+        int cnt = (e1 != 0xFFFFFFFFu ? 1 : 0) + ((k > 1 && e2 != 0xFFFFFFFFu) ? 1 : 0);
         if (e2 != 0xFFFFFFFFu) {
             const int32_t d2 = (int32_t)(e2 >> 5);
             const uint32_t x2 = (uint32_t)(d2 - qn + 2 * KEY_OFFSET) >> 1;
             bool redo = d2 >= (1 << 22) || third_x <= x2;
+            bool settled = false;  // verdict already known from the bounds
             if (redo && skip_r2 > 0.0 && d2 < (1 << 22)) {
                 // A row outside the two groups may be the true second neighbour:
                 // its squared distance is at least L3 = qn + 2 third - 2 KEY and
@@ -981,16 +985,24 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
                 const double l3 = (double)qn - 2.0 * (double)KEY_OFFSET + 2.0 * (double)third_x;
                 if (d1 < l3 && (d1 + 2.0) * (1.0 + 1e-6) < skip_r2 * l3) {
                     redo = false;  // passes whatever the second neighbour is; the record of the best is exact
+                    settled = true;
                 } else if (d1 >= skip_r2 * (double)d2 * (1.0 + 1e-6) + 2.0) {
                     redo = false;  // fails even against the farthest candidate
-                    job.counts[q] = 0;
+                    settled = true;
+                    cnt = 0;
                 }
             }
             if (redo) {
                 const int slot = atomicAdd(job.redo, 1);
                 job.redo[1 + slot] = q;
+            } else if (skip_r2 > 0.0 && !settled) {
+                // both records are final: the ratio verdict itself (main.cpp:192, in
+                // double on the float distances) goes into the count, 0 = fails, so
+                // that the compaction after this kernel reads one word per query
+                if (!((double)dist_j < ratio * (double)dist_second)) cnt = 0;
             }
         }
+        job.counts[q] = cnt;
     }
     }  // listed queries
 }
@@ -1095,7 +1107,7 @@ knn_redo_scan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int max_seg)
 }
 
 __global__ void __launch_bounds__(256)
-knn_redo_merge_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int max_seg)
+knn_redo_merge_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int max_seg, double ratio)
 {
     const KnnJob job = jobs[blockIdx.y];
     const int n_redo = job.redo[0];
@@ -1119,6 +1131,10 @@ knn_redo_merge_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int 
                 job.out[(size_t)q * k + j] = m;
             }
         }
+        // ratio verdict in the count, as the rescan kernel leaves it
+        if (ratio > 0.0 && k == 2 && a2 != NONE &&
+            !((double)__uint_as_float((uint32_t)(a1 >> 32)) < ratio * (double)__uint_as_float((uint32_t)(a2 >> 32))))
+            job.counts[q] = 0;
     }
 }
 
@@ -1266,7 +1282,7 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
 hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_query_max,
                                int n_splits, int k, int group_mode, double skip_ratio)
 {
-    const double skip_r2 = skip_ratio > 0.0 && k == 2 ? skip_ratio * skip_ratio : 0.0;
+    const double ratio = skip_ratio > 0.0 && k == 2 ? skip_ratio : 0.0;
     const int qblocks = (n_query_max + RESCAN_QPW - 1) / RESCAN_QPW;
     if (qblocks <= 0 || n_jobs <= 0) return hipSuccess;
     const long long total = (long long)qblocks * n_jobs;
@@ -1274,14 +1290,14 @@ hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs
     const int mode = n_jobs % 8 == 0 ? 1 : 0;
     if (group_mode)
         hipLaunchKernelGGL(knn_rescan_kernel<1>, dim3((unsigned)total), dim3(256), 0, s, jobs_dev, n_splits, k,
-                           qblocks, mode, skip_r2);
+                           qblocks, mode, ratio);
     else
         hipLaunchKernelGGL(knn_rescan_kernel<0>, dim3((unsigned)total), dim3(256), 0, s, jobs_dev, n_splits, k,
-                           qblocks, mode, skip_r2);
+                           qblocks, mode, ratio);
     return hipGetLastError();
 }
 
-hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_splits, int k)
+hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_splits, int k, double skip_ratio)
 {
     // flagged queries are rare: about 2048 workgroups in all are plenty, and a
     // larger grid only costs launch time
@@ -1289,7 +1305,8 @@ hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, in
     // with many jobs in flight a flagged query is cut into fewer, longer segments
     const int max_seg = std::min(REDO_MAX_SEG, std::max(1, 512 / (n_jobs > 0 ? n_jobs : 1)));
     hipLaunchKernelGGL(knn_redo_scan_kernel, dim3(gx, n_jobs), dim3(256), 0, s, jobs_dev, n_splits, max_seg);
-    hipLaunchKernelGGL(knn_redo_merge_kernel, dim3(4, n_jobs), dim3(256), 0, s, jobs_dev, n_splits, k, max_seg);
+    hipLaunchKernelGGL(knn_redo_merge_kernel, dim3(4, n_jobs), dim3(256), 0, s, jobs_dev, n_splits, k, max_seg,
+                       skip_ratio > 0.0 && k == 2 ? skip_ratio : 0.0);
     return hipGetLastError();
 }
 

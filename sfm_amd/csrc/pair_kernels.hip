@@ -31,10 +31,12 @@ __device__ __forceinline__ int compact_slot(bool flag, int* wsum, int* base)
     return flag ? b + wave_prefix + lane_prefix : -1;
 }
 
-// Ratio test verdict of query row q.
+// Ratio test verdict of query row q.  With ratio > 0 the k-NN kernels have
+// already folded it into the count (2 = passes, 0 = fails).
 __device__ __forceinline__ bool ratio_keep(const PairDev& pd, int q, double ratio)
 {
     if (pd.counts[q] < 2) return false;
+    if (ratio > 0.0) return true;
     return (double)pd.knn[2 * q].distance < ratio * (double)pd.knn[2 * q + 1].distance;
 }
 

@@ -545,7 +545,7 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
         }
         {
             ProfScope ps(ctx, "knn_redo");
-            SFM_HIP(ctx, launch_knn_redo(s, djobs, g, plan.n_splits, 2));
+            SFM_HIP(ctx, launch_knn_redo(s, djobs, g, plan.n_splits, 2, params->ratio));
         }
         {
             ProfScope ps(ctx, "ratio_compact");

@@ -130,7 +130,7 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
     }
     {
         ProfScope ps(ctx, "knn_redo");
-        SFM_HIP(ctx, launch_knn_redo(ctx->stream, ctx->jobs.as<KnnJob>(), 1, plan.n_splits, k));
+        SFM_HIP(ctx, launch_knn_redo(ctx->stream, ctx->jobs.as<KnnJob>(), 1, plan.n_splits, k, 0.0));
     }
     if (!out_on_device) {
         SFM_HIP(ctx, hipMemcpyAsync(matches, out_dev, (size_t)nq * k * sizeof(sfm_gpu_dmatch),

@@ -99,11 +99,14 @@ struct KnnPlan {
 KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant);
 hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_rows_alloc_max,
                        const KnnPlan& plan);
-// skip_ratio > 0 (k = 2 only): queries that certainly fail the ratio test
-// d1 < skip_ratio * d2 get no neighbours (counts = 0) instead of exact ones.
+// skip_ratio > 0 (k = 2 only): queries that fail the ratio test
+// d1 < skip_ratio * d2 end with counts = 0 (those that certainly fail it get no
+// exact neighbours at all); counts = 2 then means "passes".  launch_knn_redo
+// must be given the same value.
 hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_query_max,
                                int n_splits, int k, int group_mode, double skip_ratio);
-hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_splits, int k);
+hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_splits, int k,
+                           double skip_ratio);
 hipError_t launch_mfma_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c);
 hipError_t launch_sqrt_probe(hipStream_t s, int32_t* mismatches);
 hipError_t launch_mfma16_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c);
