@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--knn-variant", type=int, default=-1, help="debug: force the sweep kernel shape")
     ap.add_argument("--score-filter", type=int, default=1, help="debug: 0 = double precision only")
     ap.add_argument("--score-prune", type=int, default=1, help="debug: 0 = score every model on every point")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                    help="steps kept on the stream at once (1: collect each step before enqueueing the next)")
     ap.add_argument("--desc-u8", action="store_true",
                     help="descriptors arrive as CV_8U instead of cv::SIFT's CV_32F (not the headline configuration)")
     args = ap.parse_args()
@@ -145,8 +147,29 @@ def main():
                                    model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED,
                                    prob=0.99, threshold=3.0, n_hyp=nh)
 
-    for _ in range(args.warmup):
-        n_good, n_inl = step()
+    # The timed loop keeps up to `--in-flight` steps on the stream: step k+1
+    # (conversion + matching) is enqueued before the host collects the counts of
+    # step k, so the GPU does not idle through the host's round trip.  Every
+    # step still runs start to finish, in order, on the one stream.
+    batch = matcher.PairBatch(ctx, images, pairs, None, ratio=0.7, model=matcher.MODEL_FUNDAMENTAL,
+                              mode=matcher.RANSAC_FIXED, prob=0.99, threshold=3.0, n_hyp=nh)
+
+    def run_steps(k):
+        res, in_flight = None, 0
+        for _ in range(k):
+            prep.run()
+            batch.begin()
+            in_flight += 1
+            if in_flight == args.in_flight:
+                res = batch.end()
+                in_flight -= 1
+        while in_flight:
+            res = batch.end()
+            in_flight -= 1
+        return res
+
+    if args.warmup:
+        n_good, n_inl = run_steps(args.warmup)
     matcher.check_inputs(ctx)
 
     def fence():
@@ -160,8 +183,7 @@ def main():
     ctx.profile_reset()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_good, n_inl = step()
+    n_good, n_inl = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     knn_ms, knn_cnt = ctx.profile_query("knn2_mfma")
@@ -232,6 +254,7 @@ def main():
                             (n, n, "CV_8U" if args.desc_u8 else "CV_32F as cv::SIFT emits them", nh),
                 "pairs_per_step": B * world,
                 "pairs_per_gpu_per_step": B,
+                "steps_in_flight": args.in_flight,
                 "n_good_mean": float(np.mean(n_good)),
                 "n_inliers_mean": float(np.mean(n_inl)),
             },

@@ -277,6 +277,29 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
                         int32_t* n_inliers, sfm_gpu_dmatch* inlier_matches,
                         int match_capacity);
 
+/*
+ * The same work split into "enqueue" and "collect", so that a host can put the
+ * next batch on the stream while the previous one is still running and the GPU
+ * never waits for the host between batches.  No counterpart in the reference,
+ * whose loop finishes a pair before it starts the next (main.cpp:175-231).
+ *
+ *   sfm_gpu_match_pairs_begin  enqueues one batch (every pair must fit one
+ *                     launch group: SFM_GPU_ERR_CAPACITY otherwise, as when two
+ *                     batches are already in flight).  With mode FIXED it
+ *                     returns without waiting for the device; ADAPTIVE needs the
+ *                     host between its rounds and returns when they are done.
+ *                     The images must stay alive and unchanged until the
+ *                     matching _end; other calls on the context may be made in
+ *                     between (they queue behind the batch).
+ *   sfm_gpu_match_pairs_end    waits for the OLDEST batch in flight and returns
+ *                     its counts (capacity = room in both arrays, >= that
+ *                     batch's n_pairs).
+ * Counts only: a caller that needs the inlier records uses sfm_gpu_match_pairs.
+ */
+int sfm_gpu_match_pairs_begin(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images,
+                              const int32_t* pairs, int n_pairs, const sfm_gpu_match_params* params);
+int sfm_gpu_match_pairs_end(sfm_gpu_ctx* ctx, int32_t* n_good, int32_t* n_inliers, int capacity);
+
 /* ---- measurement support --------------------------------------------- */
 
 /*

@@ -100,10 +100,40 @@ __global__ void __launch_bounds__(1024) inlier_compact_kernel(const PairDev* __r
             if (slot >= 0 && pd.inliers && slot < pd.capacity) pd.inliers[slot] = pd.good[i];
         }
     }
-    if (threadIdx.x == 0) *pd.n_inliers = base;
+    if (threadIdx.x == 0) {
+        *pd.n_inliers = base;
+        // the caller's copy goes straight to its pinned buffer: visible to the
+        // host once it has waited for this kernel, and one copy less in the stream
+        if (pd.host_counts) {
+            pd.host_counts[0] = n;
+            pd.host_counts[1] = base;
+        }
+    }
+}
+
+// Brings one batch's descriptor block from pinned host memory (which the device
+// reads directly) into device memory and clears the jobs' redo counters: one
+// short launch in the stream instead of three copies and a fill, each of which
+// costs more in queue hand-over than in transfer.
+__global__ void __launch_bounds__(256) upload_block_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src,
+                                                           int n16, int32_t* redo, size_t redo_stride, int n_jobs)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+    if (i < n_jobs) *(int32_t*)((char*)redo + (size_t)i * redo_stride) = 0;
 }
 
 }  // namespace
+
+hipError_t launch_upload_block(hipStream_t s, void* dst, const void* src_pinned, size_t bytes, int32_t* redo,
+                               size_t redo_stride, int n_jobs)
+{
+    const int n16 = (int)((bytes + 15) / 16);
+    const int n = std::max(n16, n_jobs);
+    hipLaunchKernelGGL(upload_block_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (uint4*)dst,
+                       (const uint4*)src_pinned, n16, redo, redo_stride, n_jobs);
+    return hipGetLastError();
+}
 
 hipError_t launch_ratio_compact(hipStream_t s, const PairDev* pairs, int n_pairs, int n_query_max, double ratio)
 {

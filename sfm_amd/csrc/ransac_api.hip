@@ -113,14 +113,17 @@ int fill_params(sfm_gpu_ctx* ctx, RansacProb& pb, const RansacParams& rp)
 // the masks and models are on the device; the stream has been synchronised.
 int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int hyp_cap,
                  const RansacParams& rp, const int32_t* custom_table_host, std::vector<int32_t>& results,
-                 bool need_results)
+                 bool need_results, RansacProb* dprobs_ready = nullptr)
 {
     const int n_prob = (int)probs.size();
     const int m = probs[0].m;
     hipStream_t s = ctx->stream;
-    SFM_HIP(ctx, ctx->rs_misc.reserve(sizeof(RansacProb) * (size_t)n_prob));
-    RansacProb* dprobs = ctx->rs_misc.as<RansacProb>();
-    SFM_HIP(ctx, hipMemcpyAsync(dprobs, probs.data(), sizeof(RansacProb) * n_prob, hipMemcpyHostToDevice, s));
+    RansacProb* dprobs = dprobs_ready;  // the caller may have uploaded `probs` with its own descriptors
+    if (!dprobs) {
+        SFM_HIP(ctx, ctx->rs_misc.reserve(sizeof(RansacProb) * (size_t)n_prob));
+        dprobs = ctx->rs_misc.as<RansacProb>();
+        SFM_HIP(ctx, ctx->upload(dprobs, probs.data(), sizeof(RansacProb) * n_prob));
+    }
     {
         ProfScope ps(ctx, "ransac_prep");
         SFM_HIP(ctx, launch_ransac_prep(s, dprobs, n_prob, cap));
@@ -409,6 +412,210 @@ int sfm_gpu_debug_ransac_dump(sfm_gpu_ctx* ctx, int n_hyp, int32_t* table, int32
     return SFM_GPU_OK;
 }
 
+// Everything sfm_gpu_match_pairs needs to know before it touches the stream.
+struct MpPlan {
+    RansacParams rp;
+    RansacProb proto;
+    int m = 0, hyp_cap = 0, nq_max = 1, nt_max = 1, qalloc_max = ROW_ALIGN, group = 1;
+    size_t per_pair_ransac = 0, out_b = 0, cnt_b = 0, redo_b = 0, good_b = 0, px_b = 0, inl_b = 0;
+};
+
+static int mp_plan(sfm_gpu_ctx* ctx, MpPlan& pl, sfm_gpu_image* const* images, int n_images, const int32_t* pairs,
+                   int n_pairs, const sfm_gpu_match_params* params, bool want_inliers, int match_capacity)
+{
+    for (int p = 0; p < 2 * n_pairs; ++p)
+        if (pairs[p] < 0 || pairs[p] >= n_images)
+            return ctx->fail(SFM_GPU_ERR_ARG, "pair %d names image %d of %d", p / 2, pairs[p], n_images);
+    RansacParams& rp = pl.rp;
+    rp.model = params->model;
+    rp.mode = params->mode;
+    memcpy(rp.K, params->K, sizeof(rp.K));
+    rp.prob = params->prob;
+    rp.threshold_px = params->threshold_px;
+    rp.max_iters = params->max_iters;
+    rp.n_hyp = params->n_hyp;
+    int rc = fill_params(ctx, pl.proto, rp);
+    if (rc) return rc;
+    pl.m = pl.proto.m;
+    pl.hyp_cap = rp.mode == SFM_GPU_RANSAC_FIXED ? rp.n_hyp : std::max(rp.max_iters, 1);
+    for (int p = 0; p < n_pairs; ++p) {
+        const sfm_gpu_image* iq = images[pairs[2 * p]];
+        const sfm_gpu_image* it = images[pairs[2 * p + 1]];
+        if (!iq || !it) return ctx->fail(SFM_GPU_ERR_ARG, "null image in pair %d", p);
+        if (!iq->d.kp || !it->d.kp)
+            return ctx->fail(SFM_GPU_ERR_ARG, "pair %d: images need keypoints for RANSAC", p);
+        pl.nq_max = std::max(pl.nq_max, iq->d.n);
+        pl.nt_max = std::max(pl.nt_max, it->d.n);
+        pl.qalloc_max = std::max(pl.qalloc_max, iq->d.rows_alloc);
+    }
+    if (want_inliers && match_capacity < pl.nq_max)
+        return ctx->fail(SFM_GPU_ERR_CAPACITY, "match_capacity %d < largest query image %d",
+                         match_capacity, pl.nq_max);
+    // pairs are processed in groups that share one launch per stage
+    pl.per_pair_ransac = ransac_ws_bytes(pl.nq_max, pl.hyp_cap, pl.m);
+    int group = (int)std::min<size_t>((size_t)n_pairs,
+                                      std::max<size_t>(1, ((size_t)3 << 30) / (pl.per_pair_ransac + 1)));
+    pl.group = std::min(group, 256);
+    pl.out_b = align_up((size_t)pl.nq_max * 2 * sizeof(sfm_gpu_dmatch), 256);
+    pl.cnt_b = align_up((size_t)pl.nq_max * 4, 256);
+    pl.redo_b = align_up(((size_t)pl.nq_max + 1) * 4, 256);
+    pl.good_b = align_up((size_t)pl.nq_max * sizeof(sfm_gpu_dmatch), 256);
+    pl.px_b = align_up((size_t)pl.nq_max * 16, 256);
+    pl.inl_b = want_inliers ? align_up((size_t)match_capacity * sizeof(sfm_gpu_dmatch), 256) : 0;
+    return SFM_GPU_OK;
+}
+
+// Bytes of one group's descriptor block: the three arrays back to back, each
+// starting on a 64-byte boundary (device block and pinned staging alike).
+static size_t mp_stage_bytes(int g)
+{
+    return align_up(sizeof(KnnJob) * (size_t)g, 64) + align_up(sizeof(PairDev) * (size_t)g, 64) +
+           align_up(sizeof(RansacProb) * (size_t)g, 64) + 64;
+}
+
+static int mp_reserve(sfm_gpu_ctx* ctx, const MpPlan& pl)
+{
+    const size_t group = (size_t)pl.group;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, ctx->out.reserve(pl.out_b * group));
+    SFM_HIP(ctx, ctx->counts.reserve(pl.cnt_b * group));
+    SFM_HIP(ctx, ctx->redo.reserve(pl.redo_b * group));
+    SFM_HIP(ctx, ctx->mp_good.reserve((pl.good_b + pl.inl_b) * group));
+    SFM_HIP(ctx, ctx->mp_pts.reserve(pl.px_b * 2 * group));
+    SFM_HIP(ctx, ctx->mp_ngood.reserve(8 * group));
+    SFM_HIP(ctx, ctx->rs_counts.reserve((size_t)R_COUNT * 4 * group));
+    SFM_HIP(ctx, ctx->rs_models.reserve(pl.per_pair_ransac * group));
+    SFM_HIP(ctx, ctx->jobs.reserve(mp_stage_bytes((int)group)));
+    return SFM_GPU_OK;
+}
+
+// Enqueues one group of pairs (g0 .. g0+g) on the context's stream; the last
+// kernel leaves the (n_good, n_inliers) words in `res_pinned` (pinned host memory).  In
+// fixed-count mode nothing here waits for the device.
+static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* images, const int32_t* pairs,
+                      int g0, int g, const sfm_gpu_match_params* params, bool want_inliers, int match_capacity,
+                      std::vector<PairDev>& pds, void* res_pinned)
+{
+    hipStream_t s = ctx->stream;
+    std::vector<KnnJob> jobs(g);
+    std::vector<RansacProb> probs(g, pl.proto);
+    std::vector<int32_t> results;
+    pds.assign(g, PairDev());
+    const KnnPlan plan = plan_knn(pl.nq_max, pl.nt_max, g, ctx->knn_variant);
+    // a smaller (last) group may be planned with more train parts per job: size
+    // the record buffer from this group's own plan
+    const size_t partial_b = align_up((size_t)plan.n_splits * pl.qalloc_max * sizeof(uint4), 256);
+    SFM_HIP(ctx, ctx->partial.reserve(partial_b * g));
+    for (int i = 0; i < g; ++i) {
+        const ImageDev& q = images[pairs[2 * (g0 + i)]]->d;
+        const ImageDev& t = images[pairs[2 * (g0 + i) + 1]]->d;
+        KnnJob& j = jobs[i];
+        j.q_desc = q.desc;
+        j.t_desc = t.desc;
+        j.t_cin = t.cin;
+        j.q_qn = q.qn;
+        j.t_qn = t.qn;
+        j.partial = (uint4*)(ctx->partial.as<char>() + partial_b * i);
+        j.out = (sfm_gpu_dmatch*)(ctx->out.as<char>() + pl.out_b * i);
+        j.counts = (int32_t*)(ctx->counts.as<char>() + pl.cnt_b * i);
+        j.redo = (int32_t*)(ctx->redo.as<char>() + pl.redo_b * i);
+        j.n_query = q.n;
+        j.n_train = t.n;
+        j.q_rows_alloc = q.rows_alloc;
+        j.t_chunks = t.n > 0 ? (t.n + CHUNK - 1) / CHUNK : 0;
+        PairDev& pd = pds[i];
+        pd.knn = j.out;
+        pd.counts = j.counts;
+        pd.kp_q = q.kp;
+        pd.kp_t = t.kp;
+        pd.good = (sfm_gpu_dmatch*)(ctx->mp_good.as<char>() + (pl.good_b + pl.inl_b) * i);
+        pd.inliers = want_inliers ? (sfm_gpu_dmatch*)((char*)pd.good + pl.good_b) : nullptr;
+        pd.px1 = (double*)(ctx->mp_pts.as<char>() + pl.px_b * 2 * i);
+        pd.px2 = (double*)(ctx->mp_pts.as<char>() + pl.px_b * 2 * i + pl.px_b);
+        pd.n_good = ctx->mp_ngood.as<int32_t>() + 2 * i;
+        pd.n_inliers = pd.n_good + 1;
+        pd.host_counts = (int32_t*)res_pinned + 2 * i;
+        pd.n_query = q.n;
+        pd.capacity = match_capacity;
+        RansacProb& pb = probs[i];
+        pb.px1 = pd.px1;
+        pb.px2 = pd.px2;
+        pb.n_ptr = pd.n_good;
+        carve_ransac(pb, ctx->rs_models.as<char>() + pl.per_pair_ransac * i, pl.nq_max, pl.hyp_cap, pl.m);
+        pb.result = ctx->rs_counts.as<int32_t>() + (size_t)R_COUNT * i;
+        pd.mask = pb.mask;
+        pd.result = pb.result;
+    }
+    // the three descriptor arrays travel as one block: one copy on the stream
+    const size_t off_pd = align_up(sizeof(KnnJob) * (size_t)g, 64);
+    const size_t off_pb = off_pd + align_up(sizeof(PairDev) * (size_t)g, 64);
+    const size_t blob_b = off_pb + sizeof(RansacProb) * (size_t)g;
+    std::vector<char> blob(blob_b);
+    memcpy(blob.data(), jobs.data(), sizeof(KnnJob) * (size_t)g);
+    memcpy(blob.data() + off_pd, pds.data(), sizeof(PairDev) * (size_t)g);
+    memcpy(blob.data() + off_pb, probs.data(), sizeof(RansacProb) * (size_t)g);
+    KnnJob* djobs = ctx->jobs.as<KnnJob>();
+    PairDev* dpds = (PairDev*)(ctx->jobs.as<char>() + off_pd);
+    RansacProb* dprobs = (RansacProb*)(ctx->jobs.as<char>() + off_pb);
+    const size_t blob_pad = align_up(blob_b, 64);
+    if (ctx->up_stage && ctx->up_used + blob_pad <= ctx->up_stage->cap) {
+        // staged in pinned memory: one short kernel copies the block and clears
+        // the redo counters that head each job's list
+        char* at = ctx->up_stage->as<char>() + ctx->up_used;
+        memcpy(at, blob.data(), blob_b);
+        ctx->up_used += blob_pad;
+        SFM_HIP(ctx, launch_upload_block(s, djobs, at, blob_b, ctx->redo.as<int32_t>(), pl.redo_b, g));
+    } else {
+        SFM_HIP(ctx, hipMemsetAsync(ctx->redo.p, 0, pl.redo_b * g, s));
+        SFM_HIP(ctx, hipMemcpyAsync(djobs, blob.data(), blob_b, hipMemcpyHostToDevice, s));
+    }
+    {
+        ProfScope ps(ctx, "knn2_mfma");
+        SFM_HIP(ctx, launch_knn2(s, djobs, g, pl.qalloc_max, plan));
+    }
+    {
+        ProfScope ps(ctx, "knn_finalize");
+        // the pair loop keeps only the ratio-test survivors: queries that
+        // certainly fail the test are not given exact neighbours
+        SFM_HIP(ctx, launch_knn_finalize(s, djobs, g, pl.nq_max, plan.n_splits, 2, plan.group_mode, params->ratio));
+    }
+    {
+        ProfScope ps(ctx, "knn_redo");
+        SFM_HIP(ctx, launch_knn_redo(s, djobs, g, plan.n_splits, 2, params->ratio));
+    }
+    {
+        ProfScope ps(ctx, "ratio_compact");
+        SFM_HIP(ctx, launch_ratio_compact(s, dpds, g, pl.nq_max, params->ratio));
+    }
+    int rc = ransac_batch(ctx, probs, pl.nq_max, pl.hyp_cap, pl.rp, nullptr, results, false, dprobs);
+    if (rc) return rc;
+    {
+        ProfScope ps(ctx, "inlier_compact");
+        SFM_HIP(ctx, launch_inlier_compact(s, dpds, g));
+    }
+    return SFM_GPU_OK;  // inlier_compact has written the counts into res_pinned
+}
+
+// Copies one group's counts out of `res` and refreshes the sizing hints.
+static void mp_collect(sfm_gpu_ctx* ctx, const int32_t* res, int g, int32_t* n_good, int32_t* n_inliers)
+{
+    double out_sum = 0.0, pts_sum = 0.0;
+    int out_cnt = 0;
+    for (int i = 0; i < g; ++i) {
+        n_good[i] = res[2 * i];
+        n_inliers[i] = res[2 * i + 1];
+        if (res[2 * i + 1] > 0) {
+            out_sum += res[2 * i] - res[2 * i + 1];
+            pts_sum += res[2 * i];
+            ++out_cnt;
+        }
+    }
+    if (out_cnt > 0) {  // sizes the next call's scoring stages
+        ctx->hint_outliers = out_sum / out_cnt;
+        ctx->hint_points = pts_sum / out_cnt;
+    }
+}
+
 int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images, const int32_t* pairs,
                         int n_pairs, const sfm_gpu_match_params* params, int32_t* n_good,
                         int32_t* n_inliers, sfm_gpu_dmatch* inlier_matches, int match_capacity)
@@ -418,170 +625,81 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
         (n_pairs > 0 && (!images || !pairs || !n_good || !n_inliers)))
         return ctx->fail(SFM_GPU_ERR_ARG, "null pointer or negative count");
     if (n_pairs == 0) return SFM_GPU_OK;
-    for (int p = 0; p < 2 * n_pairs; ++p)
-        if (pairs[p] < 0 || pairs[p] >= n_images)
-            return ctx->fail(SFM_GPU_ERR_ARG, "pair %d names image %d of %d", p / 2, pairs[p], n_images);
-    RansacParams rp;
-    rp.model = params->model;
-    rp.mode = params->mode;
-    memcpy(rp.K, params->K, sizeof(rp.K));
-    rp.prob = params->prob;
-    rp.threshold_px = params->threshold_px;
-    rp.max_iters = params->max_iters;
-    rp.n_hyp = params->n_hyp;
-    RansacProb proto;
-    int rc = fill_params(ctx, proto, rp);
+    MpPlan pl;
+    int rc = mp_plan(ctx, pl, images, n_images, pairs, n_pairs, params, inlier_matches != nullptr, match_capacity);
     if (rc) return rc;
-    const int m = proto.m;
-    const int hyp_cap = rp.mode == SFM_GPU_RANSAC_FIXED ? rp.n_hyp : std::max(rp.max_iters, 1);
-    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    rc = mp_reserve(ctx, pl);
+    if (rc) return rc;
     hipStream_t s = ctx->stream;
-
-    int nq_max = 1, nt_max = 1, qalloc_max = ROW_ALIGN;
-    for (int p = 0; p < n_pairs; ++p) {
-        const sfm_gpu_image* iq = images[pairs[2 * p]];
-        const sfm_gpu_image* it = images[pairs[2 * p + 1]];
-        if (!iq || !it) return ctx->fail(SFM_GPU_ERR_ARG, "null image in pair %d", p);
-        if (!iq->d.kp || !it->d.kp)
-            return ctx->fail(SFM_GPU_ERR_ARG, "pair %d: images need keypoints for RANSAC", p);
-        nq_max = std::max(nq_max, iq->d.n);
-        nt_max = std::max(nt_max, it->d.n);
-        qalloc_max = std::max(qalloc_max, iq->d.rows_alloc);
-    }
-    if (inlier_matches && match_capacity < nq_max)
-        return ctx->fail(SFM_GPU_ERR_CAPACITY, "match_capacity %d < largest query image %d",
-                         match_capacity, nq_max);
-
-    // pairs are processed in groups that share one launch per stage
-    const size_t per_pair_ransac = ransac_ws_bytes(nq_max, hyp_cap, m);
-    int group = (int)std::min<size_t>((size_t)n_pairs,
-                                      std::max<size_t>(1, ((size_t)3 << 30) / (per_pair_ransac + 1)));
-    group = std::min(group, 256);
-    const size_t out_b = align_up((size_t)nq_max * 2 * sizeof(sfm_gpu_dmatch), 256);
-    const size_t cnt_b = align_up((size_t)nq_max * 4, 256);
-    const size_t redo_b = align_up(((size_t)nq_max + 1) * 4, 256);
-    const size_t good_b = align_up((size_t)nq_max * sizeof(sfm_gpu_dmatch), 256);
-    const size_t px_b = align_up((size_t)nq_max * 16, 256);
-    const size_t inl_b = inlier_matches ? align_up((size_t)match_capacity * sizeof(sfm_gpu_dmatch), 256) : 0;
-    SFM_HIP(ctx, ctx->out.reserve(out_b * group));
-    SFM_HIP(ctx, ctx->counts.reserve(cnt_b * group));
-    SFM_HIP(ctx, ctx->redo.reserve(redo_b * group));
-    SFM_HIP(ctx, ctx->mp_good.reserve((good_b + inl_b) * group));
-    SFM_HIP(ctx, ctx->mp_pts.reserve(px_b * 2 * group));
-    SFM_HIP(ctx, ctx->mp_ngood.reserve(8 * (size_t)group));
-    SFM_HIP(ctx, ctx->rs_counts.reserve((size_t)R_COUNT * 4 * group));
-    SFM_HIP(ctx, ctx->rs_models.reserve(per_pair_ransac * group));
-    SFM_HIP(ctx, ctx->jobs.reserve((sizeof(KnnJob) + sizeof(PairDev)) * (size_t)group));
-
-    std::vector<KnnJob> jobs;
+    SFM_HIP(ctx, ctx->mp_stage_sync.reserve(mp_stage_bytes(pl.group)));
+    SFM_HIP(ctx, ctx->mp_res_sync.reserve(8 * (size_t)pl.group));
     std::vector<PairDev> pds;
-    std::vector<RansacProb> probs;
-    std::vector<int32_t> results;
-    std::vector<int32_t> ng(group * 2);
-    for (int g0 = 0; g0 < n_pairs; g0 += group) {
-        const int g = std::min(group, n_pairs - g0);
-        jobs.assign(g, KnnJob());
-        pds.assign(g, PairDev());
-        probs.assign(g, proto);
-        const KnnPlan plan = plan_knn(nq_max, nt_max, g, ctx->knn_variant);
-        // a smaller (last) group may be planned with more train parts per job: size
-        // the record buffer from this group's own plan
-        const size_t partial_b = align_up((size_t)plan.n_splits * qalloc_max * sizeof(uint4), 256);
-        SFM_HIP(ctx, ctx->partial.reserve(partial_b * g));
-        for (int i = 0; i < g; ++i) {
-            const ImageDev& q = images[pairs[2 * (g0 + i)]]->d;
-            const ImageDev& t = images[pairs[2 * (g0 + i) + 1]]->d;
-            KnnJob& j = jobs[i];
-            j.q_desc = q.desc;
-            j.t_desc = t.desc;
-            j.t_cin = t.cin;
-            j.q_qn = q.qn;
-            j.t_qn = t.qn;
-            j.partial = (uint4*)(ctx->partial.as<char>() + partial_b * i);
-            j.out = (sfm_gpu_dmatch*)(ctx->out.as<char>() + out_b * i);
-            j.counts = (int32_t*)(ctx->counts.as<char>() + cnt_b * i);
-            j.redo = (int32_t*)(ctx->redo.as<char>() + redo_b * i);
-            j.n_query = q.n;
-            j.n_train = t.n;
-            j.q_rows_alloc = q.rows_alloc;
-            j.t_chunks = t.n > 0 ? (t.n + CHUNK - 1) / CHUNK : 0;
-            PairDev& pd = pds[i];
-            pd.knn = j.out;
-            pd.counts = j.counts;
-            pd.kp_q = q.kp;
-            pd.kp_t = t.kp;
-            pd.good = (sfm_gpu_dmatch*)(ctx->mp_good.as<char>() + (good_b + inl_b) * i);
-            pd.inliers = inlier_matches ? (sfm_gpu_dmatch*)((char*)pd.good + good_b) : nullptr;
-            pd.px1 = (double*)(ctx->mp_pts.as<char>() + px_b * 2 * i);
-            pd.px2 = (double*)(ctx->mp_pts.as<char>() + px_b * 2 * i + px_b);
-            pd.n_good = ctx->mp_ngood.as<int32_t>() + 2 * i;
-            pd.n_inliers = pd.n_good + 1;
-            pd.n_query = q.n;
-            pd.capacity = match_capacity;
-            RansacProb& pb = probs[i];
-            pb.px1 = pd.px1;
-            pb.px2 = pd.px2;
-            pb.n_ptr = pd.n_good;
-            carve_ransac(pb, ctx->rs_models.as<char>() + per_pair_ransac * i, nq_max, hyp_cap, m);
-            pb.result = ctx->rs_counts.as<int32_t>() + (size_t)R_COUNT * i;
-            pd.mask = pb.mask;
-            pd.result = pb.result;
-        }
-        // one clear for all redo counters of the group (they head each job's list)
-        SFM_HIP(ctx, hipMemsetAsync(ctx->redo.p, 0, redo_b * g, s));
-        KnnJob* djobs = ctx->jobs.as<KnnJob>();
-        PairDev* dpds = (PairDev*)(ctx->jobs.as<char>() + sizeof(KnnJob) * (size_t)group);
-        SFM_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), sizeof(KnnJob) * g, hipMemcpyHostToDevice, s));
-        SFM_HIP(ctx, hipMemcpyAsync(dpds, pds.data(), sizeof(PairDev) * g, hipMemcpyHostToDevice, s));
-        {
-            ProfScope ps(ctx, "knn2_mfma");
-            SFM_HIP(ctx, launch_knn2(s, djobs, g, qalloc_max, plan));
-        }
-        {
-            ProfScope ps(ctx, "knn_finalize");
-            // the pair loop keeps only the ratio-test survivors: queries that
-            // certainly fail the test are not given exact neighbours
-            SFM_HIP(ctx, launch_knn_finalize(s, djobs, g, nq_max, plan.n_splits, 2, plan.group_mode, params->ratio));
-        }
-        {
-            ProfScope ps(ctx, "knn_redo");
-            SFM_HIP(ctx, launch_knn_redo(s, djobs, g, plan.n_splits, 2, params->ratio));
-        }
-        {
-            ProfScope ps(ctx, "ratio_compact");
-            SFM_HIP(ctx, launch_ratio_compact(s, dpds, g, nq_max, params->ratio));
-        }
-        rc = ransac_batch(ctx, probs, nq_max, hyp_cap, rp, nullptr, results, false);
+    for (int g0 = 0; g0 < n_pairs; g0 += pl.group) {
+        const int g = std::min(pl.group, n_pairs - g0);
+        ctx->up_stage = &ctx->mp_stage_sync;  // the previous group has been waited for
+        ctx->up_used = 0;
+        rc = mp_enqueue(ctx, pl, images, pairs, g0, g, params, inlier_matches != nullptr, match_capacity, pds,
+                        ctx->mp_res_sync.p);
+        ctx->up_stage = nullptr;
         if (rc) return rc;
-        {
-            ProfScope ps(ctx, "inlier_compact");
-            SFM_HIP(ctx, launch_inlier_compact(s, dpds, g));
-        }
-        SFM_HIP(ctx, ctx->pin_a.reserve(8 * (size_t)g));
-        SFM_HIP(ctx, hipMemcpyAsync(ctx->pin_a.p, ctx->mp_ngood.p, 8 * (size_t)g, hipMemcpyDeviceToHost, s));
         SFM_HIP(ctx, hipStreamSynchronize(s));
-        std::memcpy(ng.data(), ctx->pin_a.p, 8 * (size_t)g);
-        double out_sum = 0.0, pts_sum = 0.0;
-        int out_cnt = 0;
-        for (int i = 0; i < g; ++i) {
-            n_good[g0 + i] = ng[2 * i];
-            n_inliers[g0 + i] = ng[2 * i + 1];
-            if (ng[2 * i + 1] > 0) {
-                out_sum += ng[2 * i] - ng[2 * i + 1];
-                pts_sum += ng[2 * i];
-                ++out_cnt;
-            }
-            if (inlier_matches && ng[2 * i + 1] > 0)
-                SFM_HIP(ctx, hipMemcpyAsync(inlier_matches + (size_t)(g0 + i) * match_capacity,
-                                            pds[i].inliers, (size_t)ng[2 * i + 1] * sizeof(sfm_gpu_dmatch),
-                                            hipMemcpyDeviceToHost, s));
+        mp_collect(ctx, ctx->mp_res_sync.as<int32_t>(), g, n_good + g0, n_inliers + g0);
+        if (inlier_matches) {
+            for (int i = 0; i < g; ++i)
+                if (n_inliers[g0 + i] > 0)
+                    SFM_HIP(ctx, hipMemcpyAsync(inlier_matches + (size_t)(g0 + i) * match_capacity,
+                                                pds[i].inliers, (size_t)n_inliers[g0 + i] * sizeof(sfm_gpu_dmatch),
+                                                hipMemcpyDeviceToHost, s));
+            SFM_HIP(ctx, hipStreamSynchronize(s));
         }
-        if (out_cnt > 0) {  // sizes the next call's scoring stages
-            ctx->hint_outliers = out_sum / out_cnt;
-            ctx->hint_points = pts_sum / out_cnt;
-        }
-        SFM_HIP(ctx, hipStreamSynchronize(s));
     }
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_match_pairs_begin(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images,
+                              const int32_t* pairs, int n_pairs, const sfm_gpu_match_params* params)
+{
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    if (n_pairs < 1 || n_images < 0 || !params || !images || !pairs)
+        return ctx->fail(SFM_GPU_ERR_ARG, "null pointer or no pairs");
+    if (ctx->mp_outstanding >= 2)
+        return ctx->fail(SFM_GPU_ERR_CAPACITY, "two batches are already in flight: call sfm_gpu_match_pairs_end first");
+    MpPlan pl;
+    int rc = mp_plan(ctx, pl, images, n_images, pairs, n_pairs, params, false, 0);
+    if (rc) return rc;
+    if (pl.group < n_pairs)
+        return ctx->fail(SFM_GPU_ERR_CAPACITY, "%d pairs of this size do not fit one batch (%d at most)", n_pairs,
+                         pl.group);
+    rc = mp_reserve(ctx, pl);
+    if (rc) return rc;
+    sfm_gpu_ctx::MpSlot& slot = ctx->mp_slot[ctx->mp_next];
+    if (!slot.ev) SFM_HIP(ctx, hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
+    SFM_HIP(ctx, slot.stage.reserve(mp_stage_bytes(n_pairs)));
+    SFM_HIP(ctx, slot.res.reserve(8 * (size_t)n_pairs));
+    std::vector<PairDev> pds;
+    ctx->up_stage = &slot.stage;  // this slot's previous batch has been ended
+    ctx->up_used = 0;
+    rc = mp_enqueue(ctx, pl, images, pairs, 0, n_pairs, params, false, 0, pds, slot.res.p);
+    ctx->up_stage = nullptr;
+    if (rc) return rc;
+    SFM_HIP(ctx, hipEventRecord(slot.ev, ctx->stream));
+    slot.n_pairs = n_pairs;
+    ctx->mp_next ^= 1;
+    ++ctx->mp_outstanding;
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_match_pairs_end(sfm_gpu_ctx* ctx, int32_t* n_good, int32_t* n_inliers, int capacity)
+{
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    if (!n_good || !n_inliers) return ctx->fail(SFM_GPU_ERR_ARG, "null pointer");
+    if (ctx->mp_outstanding < 1) return ctx->fail(SFM_GPU_ERR_ARG, "no batch in flight");
+    sfm_gpu_ctx::MpSlot& slot = ctx->mp_slot[ctx->mp_outstanding == 2 ? ctx->mp_next : ctx->mp_next ^ 1];
+    if (capacity < slot.n_pairs)
+        return ctx->fail(SFM_GPU_ERR_CAPACITY, "the oldest batch has %d pairs, room for %d", slot.n_pairs, capacity);
+    SFM_HIP(ctx, hipEventSynchronize(slot.ev));
+    --ctx->mp_outstanding;
+    mp_collect(ctx, slot.res.as<int32_t>(), slot.n_pairs, n_good, n_inliers);
     return SFM_GPU_OK;
 }
 

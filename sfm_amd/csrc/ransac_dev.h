@@ -80,11 +80,15 @@ struct PairDev {
     const int32_t* result;      // RANSAC result block
     sfm_gpu_dmatch* inliers;    // [capacity] or null
     int32_t* n_inliers;         // [1]
+    int32_t* host_counts;       // [2] pinned host memory: (n_good, n_inliers) for the caller, or null
     int32_t n_query;
     int32_t capacity;
 };
 
 hipError_t launch_ratio_compact(hipStream_t s, const PairDev* pairs, int n_pairs, int n_query_max, double ratio);
+// dst and src_pinned are 16-byte aligned and padded to a multiple of 16 bytes
+hipError_t launch_upload_block(hipStream_t s, void* dst, const void* src_pinned, size_t bytes, int32_t* redo,
+                               size_t redo_stride, int n_jobs);
 hipError_t launch_inlier_compact(hipStream_t s, const PairDev* pairs, int n_pairs);
 
 }  // namespace sfm

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <string>
 
@@ -134,6 +135,32 @@ struct sfm_gpu_ctx {
     // recover_pose workspaces
     sfm::DevBuf pose_in, pose_out;
     int32_t dbg_pose_votes[4] = {0, 0, 0, 0};
+    // Small host-to-device uploads (job descriptors) go through pinned staging
+    // when a stage is set: a copy from pageable memory makes the host wait for
+    // the stream, which would defeat queueing one batch behind another.
+    sfm::PinnedBuf* up_stage = nullptr;
+    size_t up_used = 0;
+    hipError_t upload(void* dst, const void* src, size_t bytes)
+    {
+        const size_t need = (bytes + 63) & ~(size_t)63;
+        if (up_stage && up_used + need <= up_stage->cap) {
+            char* at = up_stage->as<char>() + up_used;
+            memcpy(at, src, bytes);
+            up_used += need;
+            return hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, stream);
+        }
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+    }
+    // sfm_gpu_match_pairs_begin / _end: up to two batches in flight
+    struct MpSlot {
+        hipEvent_t ev = nullptr;
+        sfm::PinnedBuf stage, res;
+        int n_pairs = 0;
+    };
+    MpSlot mp_slot[2];
+    int mp_next = 0;         // slot the next begin takes
+    int mp_outstanding = 0;  // begun and not yet ended (the oldest is mp_next - mp_outstanding)
+    sfm::PinnedBuf mp_stage_sync, mp_res_sync;
     // outliers (points - inliers) per problem at the end of the last RANSAC call, -1: none yet
     double hint_outliers = -1.0;
     double hint_points = -1.0;  // correspondences per problem in the previous call (as hint_outliers)

@@ -194,6 +194,13 @@ void sfm_gpu_destroy(sfm_gpu_ctx* c)
     c->tmp_t.release();
     c->pin_a.release();
     c->pin_b.release();
+    c->mp_stage_sync.release();
+    c->mp_res_sync.release();
+    for (auto& slot : c->mp_slot) {
+        if (slot.ev) (void)hipEventDestroy(slot.ev);
+        slot.stage.release();
+        slot.res.release();
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -284,13 +284,7 @@ def knn_match_images(ctx, query_img, train_img, k=2, out_device=None):
     return matches, counts
 
 
-def match_pairs(ctx, images, pairs, K, ratio=0.7, model=MODEL_ESSENTIAL, mode=RANSAC_ADAPTIVE,
-                prob=0.99, threshold=1.0, max_iters=1000, n_hyp=0, want_matches=False):
-    """The loop body of match() (main.cpp:175-231, 267) over a list of pairs.
-    Returns (n_good, n_inliers[, inlier_matches list])."""
-    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
-    n_pairs = pairs.shape[0]
-    arr = (ctypes.c_void_p * len(images))(*[im.handle for im in images])
+def _match_params(K, ratio, model, mode, prob, threshold, max_iters, n_hyp):
     p = MatchParams()
     p.ratio = ratio
     p.model = model
@@ -302,6 +296,43 @@ def match_pairs(ctx, images, pairs, K, ratio=0.7, model=MODEL_ESSENTIAL, mode=RA
     p.threshold_px = threshold
     p.max_iters = max_iters
     p.n_hyp = n_hyp
+    return p
+
+
+class PairBatch:
+    """One batch of pairs with its argument block built once, for hosts that
+    keep the GPU fed: begin() puts the batch on the stream and returns (fixed
+    mode), end() waits for the oldest batch begun on the context and returns
+    its (n_good, n_inliers).  At most two batches may be in flight."""
+
+    def __init__(self, ctx, images, pairs, K, ratio=0.7, model=MODEL_ESSENTIAL, mode=RANSAC_ADAPTIVE,
+                 prob=0.99, threshold=1.0, max_iters=1000, n_hyp=0):
+        self.ctx = ctx
+        self._images = list(images)             # keeps the handles alive
+        self._pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        self.n_pairs = self._pairs.shape[0]
+        self._arr = (ctypes.c_void_p * len(images))(*[im.handle for im in images])
+        self._p = _match_params(K, ratio, model, mode, prob, threshold, max_iters, n_hyp)
+        self._args = (ctx.handle, self._arr, len(images), ptr(self._pairs), self.n_pairs, ctypes.byref(self._p))
+
+    def begin(self):
+        self.ctx.check(self.ctx._L.sfm_gpu_match_pairs_begin(*self._args))
+
+    def end(self):
+        n_good = np.zeros(self.n_pairs, dtype=np.int32)
+        n_inl = np.zeros(self.n_pairs, dtype=np.int32)
+        self.ctx.check(self.ctx._L.sfm_gpu_match_pairs_end(self.ctx.handle, ptr(n_good), ptr(n_inl), self.n_pairs))
+        return n_good, n_inl
+
+
+def match_pairs(ctx, images, pairs, K, ratio=0.7, model=MODEL_ESSENTIAL, mode=RANSAC_ADAPTIVE,
+                prob=0.99, threshold=1.0, max_iters=1000, n_hyp=0, want_matches=False):
+    """The loop body of match() (main.cpp:175-231, 267) over a list of pairs.
+    Returns (n_good, n_inliers[, inlier_matches list])."""
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    n_pairs = pairs.shape[0]
+    arr = (ctypes.c_void_p * len(images))(*[im.handle for im in images])
+    p = _match_params(K, ratio, model, mode, prob, threshold, max_iters, n_hyp)
     n_good = np.zeros(n_pairs, dtype=np.int32)
     n_inl = np.zeros(n_pairs, dtype=np.int32)
     cap = 0

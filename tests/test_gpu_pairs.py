@@ -281,3 +281,49 @@ def test_images_prepared_in_device_memory_match_owned_images(gpu_ctx, dtype):
             assert (a == b).all()
     for im in owned + wrapped:
         im.close()
+
+
+def test_batches_in_flight_return_what_the_blocking_call_returns(gpu_ctx):
+    """begin/end with two batches on the stream at once, a blocking call queued
+    between them, and the misuse errors."""
+    from sfm_amd import _lib
+    rng = np.random.default_rng(91)
+    pool = synth.sift_like(2500, 92)
+    images = []
+    for v in range(5):
+        n = 900 + 211 * v
+        d = np.clip(pool[rng.permutation(2500)[:n]] + rng.integers(-4, 5, (n, 128)), 0, 255).astype(np.float32)
+        kp = np.stack([rng.uniform(0, synth.IMG_W, n), rng.uniform(0, synth.IMG_H, n)], 1).astype(np.float32)
+        images.append(matcher.Image(gpu_ctx, d, kp))
+    pa = np.array([[0, 1], [1, 2], [2, 3]], np.int32)
+    pb = np.array([[4, 0], [3, 1]], np.int32)
+    kw = dict(ratio=0.8, model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED, prob=0.99,
+              threshold=3.0, n_hyp=96)
+    want_a = matcher.match_pairs(gpu_ctx, images, pa, None, **kw)
+    want_b = matcher.match_pairs(gpu_ctx, images, pb, None, **kw)
+    assert want_a[0].sum() > 0 and want_b[0].sum() > 0
+    a = matcher.PairBatch(gpu_ctx, images, pa, None, **kw)
+    b = matcher.PairBatch(gpu_ctx, images, pb, None, **kw)
+    with pytest.raises(_lib.SfmGpuError) as e:
+        a.end()                                       # nothing in flight
+    assert e.value.code == _lib.ERR_ARG
+    for _ in range(3):
+        a.begin()
+        b.begin()
+        with pytest.raises(_lib.SfmGpuError) as e:
+            a.begin()                                 # a third batch
+        assert e.value.code == _lib.ERR_CAPACITY
+        mid = matcher.match_pairs(gpu_ctx, images, pb, None, **kw)   # queues behind both
+        got_a = a.end()                               # oldest first
+        got_b = b.end()
+        for got, want in ((got_a, want_a), (got_b, want_b), (mid, want_b)):
+            assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+    # adaptive mode goes through the same entry points (begin then blocks)
+    kwa = dict(ratio=0.8, model=matcher.MODEL_ESSENTIAL, prob=0.99, threshold=1.0)
+    want = matcher.match_pairs(gpu_ctx, images, pa, synth.REF_K, **kwa)
+    c = matcher.PairBatch(gpu_ctx, images, pa, synth.REF_K, **kwa)
+    c.begin()
+    got = c.end()
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+    for im in images:
+        im.close()
