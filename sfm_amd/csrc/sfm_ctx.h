@@ -151,6 +151,16 @@ struct sfm_gpu_ctx {
         }
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
     }
+    // Ring of pinned staging blocks for calls that only enqueue (image
+    // conversion): a block is reused once the event recorded behind its upload
+    // has passed.
+    struct UpSlot {
+        sfm::PinnedBuf buf;
+        hipEvent_t ev = nullptr;
+        bool armed = false;
+    };
+    UpSlot up_ring[4];
+    int up_ring_next = 0;
     // sfm_gpu_match_pairs_begin / _end: up to two batches in flight
     struct MpSlot {
         hipEvent_t ev = nullptr;

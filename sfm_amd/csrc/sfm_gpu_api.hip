@@ -3,6 +3,7 @@
 #include <cstring>
 #include <vector>
 
+#include "ransac_dev.h"
 #include "sfm_ctx.h"
 
 using namespace sfm;
@@ -33,9 +34,22 @@ int run_prep_jobs(sfm_gpu_ctx* ctx, const std::vector<PrepJob>& jobs, int dtype,
     if (jobs.empty()) return SFM_GPU_OK;
     int rows_max = 0;
     for (const PrepJob& j : jobs) rows_max = std::max(rows_max, j.img.rows_alloc);
-    SFM_HIP(ctx, ctx->prepjobs.reserve(sizeof(PrepJob) * jobs.size()));
-    SFM_HIP(ctx, hipMemcpyAsync(ctx->prepjobs.p, jobs.data(), sizeof(PrepJob) * jobs.size(),
-                                hipMemcpyHostToDevice, ctx->stream));
+    const size_t bytes = sizeof(PrepJob) * jobs.size();
+    SFM_HIP(ctx, ctx->prepjobs.reserve(bytes + 16));
+    {
+        // job descriptors: pinned staging + a one-workgroup copy kernel, so that
+        // the call never waits for work already on the stream
+        sfm_gpu_ctx::UpSlot& u = ctx->up_ring[ctx->up_ring_next];
+        ctx->up_ring_next = (ctx->up_ring_next + 1) % 4;
+        if (u.armed) SFM_HIP(ctx, hipEventSynchronize(u.ev));
+        u.armed = false;
+        SFM_HIP(ctx, u.buf.reserve(bytes + 64));
+        if (!u.ev) SFM_HIP(ctx, hipEventCreateWithFlags(&u.ev, hipEventDisableTiming));
+        std::memcpy(u.buf.p, jobs.data(), bytes);
+        SFM_HIP(ctx, launch_upload_block(ctx->stream, ctx->prepjobs.p, u.buf.p, bytes, nullptr, 0, 0));
+        SFM_HIP(ctx, hipEventRecord(u.ev, ctx->stream));
+        u.armed = true;
+    }
     ProfScope ps(ctx, "prep_rows");
     SFM_HIP(ctx, launch_prep_rows(ctx->stream, ctx->prepjobs.as<PrepJob>(), (int)jobs.size(), rows_max,
                                   dtype, ctx->flags.as<int32_t>() + flag_slot));
@@ -196,6 +210,10 @@ void sfm_gpu_destroy(sfm_gpu_ctx* c)
     c->pin_b.release();
     c->mp_stage_sync.release();
     c->mp_res_sync.release();
+    for (auto& u : c->up_ring) {
+        if (u.ev) (void)hipEventDestroy(u.ev);
+        u.buf.release();
+    }
     for (auto& slot : c->mp_slot) {
         if (slot.ev) (void)hipEventDestroy(slot.ev);
         slot.stage.release();
