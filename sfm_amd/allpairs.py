@@ -35,6 +35,51 @@ def pair_list(n_images, mode="all"):
     raise ValueError("unknown pair mode %r" % (mode,))
 
 
+def spanning_order(counts):
+    """Order in which to chain the images, from the V x V match-count (or
+    inlier-count) matrix of an exhaustive run: the maximum spanning tree of the
+    graph whose edge weights are those counts — what /root/reference/README.md:39
+    names as the usual way to recover the capture order (the reference itself
+    reads the files in name order and leaves this out, README.md:41).
+
+    counts[i, j] and counts[j, i] are added (the matcher fills one of them, or
+    both when both directions were matched).  Prim's algorithm, grown from the
+    image with the largest total count; among equal weights the edge from the
+    earliest-visited image wins, then the lower image number, so the result is
+    deterministic.  An image no positive-count edge reaches starts a new tree.
+
+    Returns (order [V], parent [V]): images in visiting order, and for each
+    image the image it was attached to (-1 for the root of a tree)."""
+    c = np.asarray(counts, dtype=np.int64)
+    if c.ndim != 2 or c.shape[0] != c.shape[1]:
+        raise ValueError("counts must be a square matrix")
+    V = c.shape[0]
+    w = c + c.T
+    np.fill_diagonal(w, 0)
+    order = np.zeros(V, np.int32)
+    parent = np.full(V, -1, np.int32)
+    done = np.zeros(V, bool)
+    best_w = np.zeros(V, np.int64)        # heaviest edge from the tree to each outside image
+    best_from = np.full(V, -1, np.int32)
+    total = w.sum(1)
+    n = 0
+    while n < V:
+        cand = np.where(~done, best_w, -1)
+        v = int(np.argmax(cand))          # lowest index among equals
+        if cand[v] <= 0:                  # nothing reachable: root of a new tree
+            v = int(np.argmax(np.where(~done, total, -1)))
+            parent[v] = -1
+        else:
+            parent[v] = best_from[v]
+        done[v] = True
+        order[n] = v
+        n += 1
+        better = ~done & (w[v] > best_w)  # strict: earlier-visited images keep their claim
+        best_w[better] = w[v][better]
+        best_from[better] = v
+    return order, parent
+
+
 def owned_range(n_images, world, rank):
     """Contiguous block of images a rank owns (sizes differ by at most one)."""
     base, extra = divmod(int(n_images), int(world))

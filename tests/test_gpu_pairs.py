@@ -141,6 +141,9 @@ def test_allpairs_driver_single_process_equals_match_pairs(gpu_ctx):
     for (i, j), g, n in zip(pairs, ng, ni):
         assert good[i, j] == g and inl[i, j] == n
     assert good.sum() == ng.sum() and inl.sum() == ni.sum() and ng.sum() > 0
+    # the capture-order step that consumes these matrices: a spanning tree over all four images
+    order, parent = allpairs.spanning_order(inl)
+    assert sorted(order.tolist()) == [0, 1, 2, 3] and (parent >= 0).sum() == 3
     for im in owned:
         im.close()
 
