@@ -84,6 +84,12 @@ def main():
     ap.add_argument("--score-prune", type=int, default=1, help="debug: 0 = score every model on every point")
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
                     help="steps kept on the stream at once (1: collect each step before enqueueing the next)")
+    ap.add_argument("--prep-stream", type=int, default=1, choices=[0, 1],
+                    help="1: descriptor conversion of the next step on a side stream, beside the current step's "
+                         "RANSAC (never beside a sweep); 0: everything on one stream")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="contexts / HIP streams that consecutive steps alternate over (1: one stream, "
+                         "kernels never overlap and their durations are their own)")
     ap.add_argument("--desc-u8", action="store_true",
                     help="descriptors arrive as CV_8U instead of cv::SIFT's CV_32F (not the headline configuration)")
     args = ap.parse_args()
@@ -112,6 +118,9 @@ def main():
 
     B, n, nh = args.pairs_per_step, args.n_desc, args.hyps
     descs, kps = make_pairs(B, n, 1000 + 100000 * rank, args.wrong_frac)
+    row_bytes = 128 * (1 if args.desc_u8 else 4)  # densely packed rows
+    desc_dtype = matcher.DESC_U8 if args.desc_u8 else matcher.DESC_F32
+    pairs = np.array([[2 * p, 2 * p + 1] for p in range(B)], np.int32)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         host_desc = np.stack(descs)
@@ -119,58 +128,101 @@ def main():
             host_desc = host_desc.astype(np.uint8)
         d_desc = torch.from_numpy(host_desc).cuda()                # [2B, n, 128] float32 (or uint8)
         d_kp = torch.from_numpy(np.stack(kps)).cuda()              # [2B, n, 2] float32
-        blk = matcher.image_packed_bytes(n)
-        d_packed = torch.empty((2 * B, blk), dtype=torch.uint8, device="cuda")
     stream.synchronize()
-    ctx = matcher.Context(local_rank, stream=stream.cuda_stream)
-    if args.knn_variant >= 0:
-        ctx._L.sfm_gpu_debug_set_knn_variant(ctx.handle, args.knn_variant)
+    desc_ptrs = [d_desc[i].data_ptr() for i in range(2 * B)]
+    kp_ptrs = [d_kp[i].data_ptr() for i in range(2 * B)]
+    blk = matcher.image_packed_bytes(n)
+
+    class Lane:
+        """One matching context on its own stream.  A step (conversion + matching
+        of one batch) belongs to one lane.  By default the conversion of step
+        k+1 is enqueued on a side stream into a second set of packed images and
+        ordered behind the front of step k (sweep, neighbour extraction, ratio
+        test, hypothesis generation), so that it runs beside the RANSAC scoring
+        of step k (HBM-bound next to VALU-bound work) and never beside a sweep:
+        the sweep still has the chip to itself and its event-timed duration is
+        its own.  --streams 2 alternates whole steps
+        over two such lanes with no ordering between them (more pairs/s, but
+        kernels of different steps then share the chip and their individual
+        durations stop meaning anything)."""
+
+        def __init__(self, st):
+            self.stream = st
+            self.n_sets = 2 if args.prep_stream else 1
+            self.side = torch.cuda.Stream() if args.prep_stream else st
+            self.ctx = matcher.Context(local_rank, stream=st.cuda_stream)
+            self.ctx_prep = matcher.Context(local_rank, stream=self.side.cuda_stream) if args.prep_stream else self.ctx
+            if args.knn_variant >= 0:
+                self.ctx._L.sfm_gpu_debug_set_knn_variant(self.ctx.handle, args.knn_variant)
+            self.packed, self.images, self.prep, self.batch, self.ready = [], [], [], [], []
+            for _ in range(self.n_sets):
+                with torch.cuda.stream(st):
+                    d_packed = torch.empty((2 * B, blk), dtype=torch.uint8, device="cuda")
+                st.synchronize()
+                packed_ptrs = [d_packed[i].data_ptr() for i in range(2 * B)]
+                images = [matcher.WrappedImage(self.ctx, packed_ptrs[i], n) for i in range(2 * B)]
+                self.packed.append(d_packed)
+                self.images.append(images)
+                # argument arrays of the calls are built once (a C++ host holds them anyway)
+                self.prep.append(matcher.PrepareBatch(self.ctx_prep, desc_ptrs, [n] * (2 * B), row_bytes, desc_dtype,
+                                                      kp_ptrs, packed_ptrs))
+                self.batch.append(matcher.PairBatch(self.ctx, images, pairs, None, ratio=0.7,
+                                                    model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED,
+                                                    prob=0.99, threshold=3.0, n_hyp=nh))
+                self.ready.append(torch.cuda.Event())
+            self.k = 0
+            self.pending = []
+
+        def begin_step(self):
+            s = self.k % self.n_sets
+            self.k += 1
+            if args.prep_stream:
+                matcher.stream_wait_front(self.ctx_prep, self.ctx)   # beside the previous step's scoring only
+                self.prep[s].run()
+                self.ready[s].record(self.side)
+                self.stream.wait_event(self.ready[s])
+            else:
+                self.prep[s].run()
+            self.batch[s].begin()
+            self.pending.append(s)
+
+        def end_step(self):
+            return self.batch[self.pending.pop(0)].end()
+
+    lanes = [Lane(stream if i == 0 else torch.cuda.Stream()) for i in range(args.streams)]
+    ctx, images, prep = lanes[0].ctx, lanes[0].images[0], lanes[0].prep[0]
     if args.score_filter != 1:
         ctx._L.sfm_gpu_debug_set_score_filter(args.score_filter)
     if args.score_prune != 1:
         ctx._L.sfm_gpu_debug_set_score_prune(args.score_prune)
-    desc_ptrs = [d_desc[i].data_ptr() for i in range(2 * B)]
-    kp_ptrs = [d_kp[i].data_ptr() for i in range(2 * B)]
-    packed_ptrs = [d_packed[i].data_ptr() for i in range(2 * B)]
-    images = [matcher.WrappedImage(ctx, packed_ptrs[i], n) for i in range(2 * B)]
-    pairs = np.array([[2 * p, 2 * p + 1] for p in range(B)], np.int32)
-
-    row_bytes = 128 * (1 if args.desc_u8 else 4)  # densely packed rows
-    desc_dtype = matcher.DESC_U8 if args.desc_u8 else matcher.DESC_F32
-
-    # argument arrays of the conversion call are built once (a C++ host holds them anyway)
-    prep = matcher.PrepareBatch(ctx, desc_ptrs, [n] * (2 * B), row_bytes, desc_dtype, kp_ptrs, packed_ptrs)
 
     def step():
         prep.run()
+        lanes[0].ctx_prep.synchronize()
         return matcher.match_pairs(ctx, images, pairs, None, ratio=0.7,
                                    model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED,
                                    prob=0.99, threshold=3.0, n_hyp=nh)
 
-    # The timed loop keeps up to `--in-flight` steps on the stream: step k+1
+    # The timed loop keeps up to `--in-flight` steps on a lane's stream: step k+1
     # (conversion + matching) is enqueued before the host collects the counts of
     # step k, so the GPU does not idle through the host's round trip.  Every
-    # step still runs start to finish, in order, on the one stream.
-    batch = matcher.PairBatch(ctx, images, pairs, None, ratio=0.7, model=matcher.MODEL_FUNDAMENTAL,
-                              mode=matcher.RANSAC_FIXED, prob=0.99, threshold=3.0, n_hyp=nh)
-
+    # step still runs start to finish, in order, on one stream.
     def run_steps(k):
-        res, in_flight = None, 0
-        for _ in range(k):
-            prep.run()
-            batch.begin()
-            in_flight += 1
-            if in_flight == args.in_flight:
-                res = batch.end()
-                in_flight -= 1
-        while in_flight:
-            res = batch.end()
-            in_flight -= 1
+        res, pending = None, []
+        for i in range(k):
+            lane = lanes[i % len(lanes)]
+            lane.begin_step()
+            pending.append(lane)
+            if len(pending) == args.in_flight * len(lanes):
+                res = pending.pop(0).end_step()
+        while pending:
+            res = pending.pop(0).end_step()
         return res
 
     if args.warmup:
         n_good, n_inl = run_steps(args.warmup)
-    matcher.check_inputs(ctx)
+    for lane in lanes:
+        matcher.check_inputs(lane.ctx_prep)
 
     def fence():
         if world > 1:
@@ -178,18 +230,30 @@ def main():
         torch.cuda.synchronize()
 
     # timed region: HIP events only around the dominant kernel (roofline figure)
-    ctx.profile_select("knn2_mfma")
-    ctx.profile_enable(True)
-    ctx.profile_reset()
+    for lane in lanes:
+        lane.ctx.profile_select("knn2_mfma")
+        lane.ctx.profile_enable(True)
+        lane.ctx.profile_reset()
     fence()
     t0 = time.perf_counter()
     n_good, n_inl = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    knn_ms, knn_cnt = ctx.profile_query("knn2_mfma")
+    knn_ms, knn_cnt = 0.0, 0
+    for lane in lanes:
+        ms, cnt = lane.ctx.profile_query("knn2_mfma")
+        knn_ms += ms
+        knn_cnt += cnt
+        if lane.ctx is not ctx:
+            lane.ctx.profile_enable(False)
     # per-kernel breakdown from two more steps outside the timed region
     ctx.profile_select(None)
     ctx.profile_reset()
+    pctx = lanes[0].ctx_prep
+    if pctx is not ctx:
+        pctx.profile_select(None)
+        pctx.profile_enable(True)
+        pctx.profile_reset()
     for _ in range(2):
         step()
     ctx.synchronize()
@@ -197,9 +261,11 @@ def main():
     for name in ("prep_rows", "knn2_mfma", "knn_finalize", "knn_redo", "ratio_compact", "ransac_prep",
                  "ransac_table", "ransac_solve", "ransac_score", "ransac_select", "ransac_mask",
                  "inlier_compact"):
-        ms, cnt = ctx.profile_query(name)
+        ms, cnt = (pctx if name == "prep_rows" else ctx).profile_query(name)
         if cnt:
             kern[name] = {"avg_us": round(ms / cnt * 1e3, 2), "launches": cnt}
+    if pctx is not ctx:
+        pctx.profile_enable(False)
     # ceiling on this box: the same sweep with its MFMAs and LDS fragment reads
     # only (no digest, no DMA, no barrier; results are garbage and unused)
     ctx.profile_select("knn2_mfma")
@@ -254,7 +320,9 @@ def main():
                             (n, n, "CV_8U" if args.desc_u8 else "CV_32F as cv::SIFT emits them", nh),
                 "pairs_per_step": B * world,
                 "pairs_per_gpu_per_step": B,
-                "steps_in_flight": args.in_flight,
+                "steps_in_flight": args.in_flight * args.streams,
+                "streams": args.streams,
+                "conversion_on_side_stream": bool(args.prep_stream),
                 "n_good_mean": float(np.mean(n_good)),
                 "n_inliers_mean": float(np.mean(n_inl)),
             },

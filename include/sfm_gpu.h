@@ -300,6 +300,20 @@ int sfm_gpu_match_pairs_begin(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, in
                               const int32_t* pairs, int n_pairs, const sfm_gpu_match_params* params);
 int sfm_gpu_match_pairs_end(sfm_gpu_ctx* ctx, int32_t* n_good, int32_t* n_inliers, int capacity);
 
+/*
+ * Ordering between two contexts (two streams) of one device: work enqueued on
+ * `waiter` after this call starts only when the batch most recently enqueued on
+ * `source` (sfm_gpu_match_pairs / _begin, fixed-count mode) has reached its
+ * scoring pass, i.e. when its distance sweep, neighbour extraction, ratio test
+ * and hypothesis generation have finished; a no-op until `source` has enqueued
+ * a batch after the first such call.  For hosts that convert the next batch's
+ * descriptors on a second stream: the conversion is bound by HBM, the scoring
+ * by vector issue, so the two share the chip well, while the conversion beside
+ * the sweep or the neighbour extraction would only slow those down.  No
+ * counterpart in the reference.
+ */
+int sfm_gpu_stream_wait_front(sfm_gpu_ctx* waiter, sfm_gpu_ctx* source);
+
 /* ---- measurement support --------------------------------------------- */
 
 /*

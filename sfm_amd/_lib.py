@@ -85,6 +85,7 @@ def lib():
                                       c.c_int]
     L.sfm_gpu_match_pairs_begin.argtypes = [vp, vp, c.c_int, vp, c.c_int, c.POINTER(MatchParams)]
     L.sfm_gpu_match_pairs_end.argtypes = [vp, vp, vp, c.c_int]
+    L.sfm_gpu_stream_wait_front.argtypes = [vp, vp]
     L.sfm_gpu_profile_enable.argtypes = [vp, c.c_int]
     L.sfm_gpu_profile_reset.argtypes = [vp]
     L.sfm_gpu_profile_select.argtypes = [vp, c.c_char_p]

@@ -172,6 +172,11 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             int mid = 0;
             const int s1_pts = (stage1 + 127) / 128 * 128;
             if (ctx->hint_points - s1_pts >= 1024.0) mid = s1_pts + (int)(0.35 * (ctx->hint_points - s1_pts));
+            if (ctx->front_ev) {
+                // the memory-bound front of the batch ends here (see sfm_gpu_stream_wait_front)
+                SFM_HIP(ctx, hipEventRecord(ctx->front_ev, s));
+                ctx->front_recorded = true;
+            }
             ProfScope ps(ctx, "ransac_score");
             SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh, stage1, mid));
         }
@@ -686,6 +691,17 @@ int sfm_gpu_match_pairs_begin(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, in
     slot.n_pairs = n_pairs;
     ctx->mp_next ^= 1;
     ++ctx->mp_outstanding;
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_stream_wait_front(sfm_gpu_ctx* waiter, sfm_gpu_ctx* source)
+{
+    if (!waiter || !source) return SFM_GPU_ERR_ARG;
+    if (waiter->device != source->device)
+        return waiter->fail(SFM_GPU_ERR_ARG, "the two contexts are on different devices");
+    SFM_HIP(waiter, hipSetDevice(source->device));
+    if (!source->front_ev) SFM_HIP(waiter, hipEventCreateWithFlags(&source->front_ev, hipEventDisableTiming));
+    if (source->front_recorded) SFM_HIP(waiter, hipStreamWaitEvent(waiter->stream, source->front_ev, 0));
     return SFM_GPU_OK;
 }
 

@@ -171,6 +171,10 @@ struct sfm_gpu_ctx {
     int mp_next = 0;         // slot the next begin takes
     int mp_outstanding = 0;  // begun and not yet ended (the oldest is mp_next - mp_outstanding)
     sfm::PinnedBuf mp_stage_sync, mp_res_sync;
+    // recorded in front of the scoring pass of every fixed-count RANSAC batch
+    // once another context has asked to wait for it (sfm_gpu_stream_wait_front)
+    hipEvent_t front_ev = nullptr;
+    bool front_recorded = false;
     // outliers (points - inliers) per problem at the end of the last RANSAC call, -1: none yet
     double hint_outliers = -1.0;
     double hint_points = -1.0;  // correspondences per problem in the previous call (as hint_outliers)

@@ -210,6 +210,7 @@ void sfm_gpu_destroy(sfm_gpu_ctx* c)
     c->pin_b.release();
     c->mp_stage_sync.release();
     c->mp_res_sync.release();
+    if (c->front_ev) (void)hipEventDestroy(c->front_ev);
     for (auto& u : c->up_ring) {
         if (u.ev) (void)hipEventDestroy(u.ev);
         u.buf.release();

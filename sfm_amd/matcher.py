@@ -384,6 +384,12 @@ class PrepareBatch:
         self.ctx.check(self.ctx._L.sfm_gpu_image_prepare_many(*self._args))
 
 
+def stream_wait_front(waiter, source):
+    """Work enqueued on `waiter` from now on starts when the batch most recently
+    enqueued on `source` (another context, same GPU) reaches its scoring pass."""
+    waiter.check(waiter._L.sfm_gpu_stream_wait_front(waiter.handle, source.handle))
+
+
 def check_inputs(ctx):
     """Waits for the stream and raises if a prepared image held non-u8 values."""
     ctx.check(ctx._L.sfm_gpu_check_inputs(ctx.handle))

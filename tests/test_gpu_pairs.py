@@ -330,3 +330,58 @@ def test_batches_in_flight_return_what_the_blocking_call_returns(gpu_ctx):
     assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
     for im in images:
         im.close()
+
+
+def test_conversion_on_a_second_context_ordered_behind_the_front_of_a_batch(gpu_ctx):
+    """Two contexts on one GPU: descriptors of the next batch are converted on
+    the second one's stream, which is told to wait for the front of the batch in
+    flight on the first (sfm_gpu_stream_wait_front); results are those of the
+    plain sequence."""
+    import torch
+    n, n_img = 1100, 4
+    rng = np.random.default_rng(123)
+    pool = synth.sift_like(1800, 124)
+    sets = []
+    for s in range(2):                                  # two different batches of images
+        descs = [np.clip(pool[rng.permutation(1800)[:n]] + rng.integers(-4, 5, (n, 128)), 0, 255).astype(np.float32)
+                 for _ in range(n_img)]
+        kps = [np.stack([rng.uniform(0, synth.IMG_W, n), rng.uniform(0, synth.IMG_H, n)], 1).astype(np.float32)
+               for _ in range(n_img)]
+        sets.append((descs, kps))
+    pairs = np.array([[0, 1], [1, 2], [2, 3], [3, 0]], np.int32)
+    kw = dict(ratio=0.8, model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED, prob=0.99,
+              threshold=3.0, n_hyp=64)
+    want = []
+    for descs, kps in sets:
+        owned = [matcher.Image(gpu_ctx, d, k) for d, k in zip(descs, kps)]
+        want.append(matcher.match_pairs(gpu_ctx, owned, pairs, None, **kw))
+        for im in owned:
+            im.close()
+    side = matcher.Context(0)
+    matcher.stream_wait_front(side, gpu_ctx)            # nothing enqueued since: a no-op
+    lanes = []
+    for descs, kps in sets:
+        d_desc = torch.from_numpy(np.stack(descs)).cuda()
+        d_kp = torch.from_numpy(np.stack(kps)).cuda()
+        d_packed = torch.zeros((n_img, matcher.image_packed_bytes(n)), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        prep = matcher.PrepareBatch(side, [d_desc[i].data_ptr() for i in range(n_img)], [n] * n_img, 512,
+                                    matcher.DESC_F32, [d_kp[i].data_ptr() for i in range(n_img)],
+                                    [d_packed[i].data_ptr() for i in range(n_img)])
+        images = [matcher.WrappedImage(gpu_ctx, d_packed[i].data_ptr(), n) for i in range(n_img)]
+        lanes.append((prep, matcher.PairBatch(gpu_ctx, images, pairs, None, **kw), images, d_desc, d_kp, d_packed))
+    lanes[0][0].run()
+    side.synchronize()
+    for rep in range(4):
+        cur, nxt = lanes[rep % 2], lanes[(rep + 1) % 2]
+        cur[1].begin()
+        matcher.stream_wait_front(side, gpu_ctx)        # the other set's conversion beside this batch's scoring
+        nxt[0].run()
+        got = cur[1].end()
+        side.synchronize()
+        assert (got[0] == want[rep % 2][0]).all() and (got[1] == want[rep % 2][1]).all()
+    matcher.check_inputs(side)
+    for lane in lanes:
+        for im in lane[2]:
+            im.close()
+    side.close()
