@@ -137,9 +137,9 @@ def main():
         """One matching context on its own stream.  A step (conversion + matching
         of one batch) belongs to one lane.  By default the conversion of step
         k+1 is enqueued on a side stream into a second set of packed images and
-        ordered behind the front of step k (sweep, neighbour extraction, ratio
-        test, hypothesis generation), so that it runs beside the RANSAC scoring
-        of step k (HBM-bound next to VALU-bound work) and never beside a sweep:
+        ordered behind the front of step k (sweep and neighbour extraction), so
+        that it runs beside the ratio test and the RANSAC of step k (HBM-bound
+        next to latency- and VALU-bound work) and never beside a sweep:
         the sweep still has the chip to itself and its event-timed duration is
         its own.  --streams 2 alternates whole steps
         over two such lanes with no ordering between them (more pairs/s, but
@@ -177,7 +177,7 @@ def main():
             s = self.k % self.n_sets
             self.k += 1
             if args.prep_stream:
-                matcher.stream_wait_front(self.ctx_prep, self.ctx)   # beside the previous step's scoring only
+                matcher.stream_wait_front(self.ctx_prep, self.ctx)   # beside the previous step's RANSAC, not its sweep
                 self.prep[s].run()
                 self.ready[s].record(self.side)
                 self.stream.wait_event(self.ready[s])

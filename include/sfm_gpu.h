@@ -303,13 +303,13 @@ int sfm_gpu_match_pairs_end(sfm_gpu_ctx* ctx, int32_t* n_good, int32_t* n_inlier
 /*
  * Ordering between two contexts (two streams) of one device: work enqueued on
  * `waiter` after this call starts only when the batch most recently enqueued on
- * `source` (sfm_gpu_match_pairs / _begin, fixed-count mode) has reached its
- * scoring pass, i.e. when its distance sweep, neighbour extraction, ratio test
- * and hypothesis generation have finished; a no-op until `source` has enqueued
- * a batch after the first such call.  For hosts that convert the next batch's
- * descriptors on a second stream: the conversion is bound by HBM, the scoring
- * by vector issue, so the two share the chip well, while the conversion beside
- * the sweep or the neighbour extraction would only slow those down.  No
+ * `source` (sfm_gpu_match_pairs / _begin) has finished its distance sweep and
+ * its neighbour extraction; a no-op until `source` has enqueued a batch after
+ * the first such call.  For hosts that convert the next batch's descriptors on
+ * a second stream: the conversion is bound by HBM and shares the chip well with
+ * what follows in the batch (ratio test, hypothesis generation and solving:
+ * latency-bound; scoring: bound by vector issue), while beside the sweep or the
+ * neighbour extraction it would slow those down by as much as it saves.  No
  * counterpart in the reference.
  */
 int sfm_gpu_stream_wait_front(sfm_gpu_ctx* waiter, sfm_gpu_ctx* source);

@@ -172,11 +172,6 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             int mid = 0;
             const int s1_pts = (stage1 + 127) / 128 * 128;
             if (ctx->hint_points - s1_pts >= 1024.0) mid = s1_pts + (int)(0.35 * (ctx->hint_points - s1_pts));
-            if (ctx->front_ev) {
-                // the memory-bound front of the batch ends here (see sfm_gpu_stream_wait_front)
-                SFM_HIP(ctx, hipEventRecord(ctx->front_ev, s));
-                ctx->front_recorded = true;
-            }
             ProfScope ps(ctx, "ransac_score");
             SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh, stage1, mid));
         }
@@ -583,6 +578,11 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
         // the pair loop keeps only the ratio-test survivors: queries that
         // certainly fail the test are not given exact neighbours
         SFM_HIP(ctx, launch_knn_finalize(s, djobs, g, pl.nq_max, plan.n_splits, 2, plan.group_mode, params->ratio));
+    }
+    if (ctx->front_ev) {
+        // the sweep and the neighbour extraction are behind (see sfm_gpu_stream_wait_front)
+        SFM_HIP(ctx, hipEventRecord(ctx->front_ev, s));
+        ctx->front_recorded = true;
     }
     {
         ProfScope ps(ctx, "knn_redo");

@@ -171,7 +171,7 @@ struct sfm_gpu_ctx {
     int mp_next = 0;         // slot the next begin takes
     int mp_outstanding = 0;  // begun and not yet ended (the oldest is mp_next - mp_outstanding)
     sfm::PinnedBuf mp_stage_sync, mp_res_sync;
-    // recorded in front of the scoring pass of every fixed-count RANSAC batch
+    // recorded behind the sweep and the neighbour extraction of every pair batch
     // once another context has asked to wait for it (sfm_gpu_stream_wait_front)
     hipEvent_t front_ev = nullptr;
     bool front_recorded = false;

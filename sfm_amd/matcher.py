@@ -386,7 +386,7 @@ class PrepareBatch:
 
 def stream_wait_front(waiter, source):
     """Work enqueued on `waiter` from now on starts when the batch most recently
-    enqueued on `source` (another context, same GPU) reaches its scoring pass."""
+    enqueued on `source` (another context, same GPU) is past its neighbour extraction."""
     waiter.check(waiter._L.sfm_gpu_stream_wait_front(waiter.handle, source.handle))
 
 
