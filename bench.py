@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--prep-stream", type=int, default=1, choices=[0, 1],
                     help="1: descriptor conversion of the next step on a side stream, beside the current step's "
                          "RANSAC (never beside a sweep); 0: everything on one stream")
+    ap.add_argument("--no-overlap-probe", action="store_true",
+                    help="skip the two-stream reference measurement after the timed region")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="contexts / HIP streams that consecutive steps alternate over (1: one stream, "
                          "kernels never overlap and their durations are their own)")
@@ -207,7 +209,7 @@ def main():
     # (conversion + matching) is enqueued before the host collects the counts of
     # step k, so the GPU does not idle through the host's round trip.  Every
     # step still runs start to finish, in order, on one stream.
-    def run_steps(k):
+    def run_steps(k, lanes=lanes):
         res, pending = None, []
         for i in range(k):
             lane = lanes[i % len(lanes)]
@@ -266,9 +268,38 @@ def main():
             kern[name] = {"avg_us": round(ms / cnt * 1e3, 2), "launches": cnt}
     if pctx is not ctx:
         pctx.profile_enable(False)
+    # For reference, outside the timed region: the same steps alternating over
+    # two unordered streams.  More pairs/s, but the sweep then shares the chip with
+    # the other step's kernels and its own duration grows: not the headline.
+    probe = None
+    if args.streams == 1 and not args.no_overlap_probe:
+        two = [lanes[0], Lane(torch.cuda.Stream())]
+        two[1].ctx.profile_select("knn2_mfma")
+        two[1].ctx.profile_enable(True)
+        ctx.profile_select("knn2_mfma")
+        ctx.profile_enable(True)
+        run_steps(6, two)
+        torch.cuda.synchronize()
+        ctx.profile_reset()
+        two[1].ctx.profile_reset()
+        k2 = max(10, min(args.steps, 40))
+        t1 = time.perf_counter()
+        run_steps(k2, two)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        ms_a, cnt_a = ctx.profile_query("knn2_mfma")
+        ms_b, cnt_b = two[1].ctx.profile_query("knn2_mfma")
+        ctx.profile_enable(False)
+        two[1].ctx.profile_enable(False)
+        probe = {"pairs_per_s": round(B * k2 / dt, 1), "ms_per_step": round(dt / k2 * 1e3, 3), "steps": k2,
+                 "knn2_avg_launch_us": round((ms_a + ms_b) / max(cnt_a + cnt_b, 1) * 1e3, 2),
+                 "what": "this rank, steps alternating over two unordered streams (bench.py --streams 2); "
+                         "kernels of different steps overlap, so per-kernel durations are not the kernels' own"}
+
     # ceiling on this box: the same sweep with its MFMAs and LDS fragment reads
     # only (no digest, no DMA, no barrier; results are garbage and unused)
     ctx.profile_select("knn2_mfma")
+    ctx.profile_enable(True)
     ctx.profile_reset()
     ctx._L.sfm_gpu_debug_set_knn_variant(ctx.handle, (args.knn_variant if args.knn_variant >= 0 else 4) + 16 * 4)
     for _ in range(0 if args.no_microkernel else 3):
@@ -351,6 +382,7 @@ def main():
                 },
             },
             "kernels_outside_timed_region": kern,
+            "two_unordered_streams_outside_timed_region": probe,
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU leg belongs to the single-GPU line only
             threads = int(os.environ.get("OMP_NUM_THREADS", "8"))
