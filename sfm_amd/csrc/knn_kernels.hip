@@ -947,8 +947,11 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
         e2 = umin32(umax32(e1, b1), umin32(e2, b2));
         e1 = lo;
     }
-    const int row1 = row_of((int)(e1 & 31u));
-    const int row2 = row_of((int)(e2 & 31u));
+    // the rows of the two winners, from the lanes that hold them (lane of
+    // position p: segment p >> 2 is the lane's low three bits, p & 3 its high two)
+    const int p1 = (int)(e1 & 31u), p2 = (int)(e2 & 31u);
+    const int row1 = __shfl(row, ((p1 & 3) << 3) | (p1 >> 2), 32);
+    const int row2 = __shfl(row, ((p2 & 3) << 3) | (p2 >> 2), 32);
     // lane j < k writes neighbour j
     const uint32_t ej = l == 0 ? e1 : e2;
     const float dist_j = sqrt_d2(ej >> 5);
