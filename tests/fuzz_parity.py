@@ -213,12 +213,22 @@ def trial_pairs(ctx, rng, idx, stats):
     thr = 3.0 if model else 1.0
     K = None if model else synth.REF_K
     fixed = bool(rng.integers(0, 2))
-    imgs = [matcher.Image(ctx, d, k) for d, k in zip(descs, kps)]
+    as_u8 = bool(rng.integers(0, 2))
+    imgs = [matcher.Image(ctx, d.astype(np.uint8) if as_u8 else d, k) for d, k in zip(descs, kps)]
+    kw = dict(ratio=ratio, model=model, mode=matcher.RANSAC_FIXED if fixed else matcher.RANSAC_ADAPTIVE,
+              prob=0.99, threshold=thr, n_hyp=nh if fixed else 0, max_iters=300)
     try:
-        ng, ni, sel = matcher.match_pairs(ctx, imgs, pairs, K, ratio=ratio, model=model,
-                                          mode=matcher.RANSAC_FIXED if fixed else matcher.RANSAC_ADAPTIVE,
-                                          prob=0.99, threshold=thr, n_hyp=nh if fixed else 0, max_iters=300,
-                                          want_matches=True)
+        ng, ni, sel = matcher.match_pairs(ctx, imgs, pairs, K, want_matches=True, **kw)
+        if rng.integers(0, 2):
+            # the same batch through the enqueue / collect entry points, twice in flight
+            b = matcher.PairBatch(ctx, imgs, pairs, K, **kw)
+            b.begin()
+            b.begin()
+            for _ in range(2):
+                g2, i2 = b.end()
+                if not ((g2 == ng).all() and (i2 == ni).all()):
+                    print("MISMATCH pairs #%d: begin/end counts differ from the blocking call" % idx, flush=True)
+                    return 1
     finally:
         for im in imgs:
             im.close()
