@@ -68,19 +68,33 @@ __global__ void __launch_bounds__(1024) ratio_compact_kernel(const PairDev* __re
     const int q = tile * 1024 + tid;
     const bool flag = q < pd.n_query && ratio_keep(pd, q, ratio);
     const int slot = compact_slot(flag, wsum, &base);
+    // with a RANSAC problem attached, its points are prepared here (Point2f
+    // widened to double as at main.cpp:194-195, then what ransac_prep_kernel
+    // would do) instead of travelling through the pixel arrays
+    const bool fused = pd.prob != nullptr;
+    RansacProb pb;
+    if (fused) pb = *pd.prob;
     if (slot >= 0) {
         const sfm_gpu_dmatch m0 = pd.knn[2 * q];
         pd.good[slot] = m0;
         if (pd.kp_q && pd.kp_t) {
             const float2 a = pd.kp_q[m0.queryIdx];
             const float2 b = pd.kp_t[m0.trainIdx];
-            pd.px1[2 * slot] = (double)a.x;
-            pd.px1[2 * slot + 1] = (double)a.y;
-            pd.px2[2 * slot] = (double)b.x;
-            pd.px2[2 * slot + 1] = (double)b.y;
+            if (fused) {
+                ransac_prep_point(pb, slot, (double)a.x, (double)a.y, (double)b.x, (double)b.y);
+            } else {
+                pd.px1[2 * slot] = (double)a.x;
+                pd.px1[2 * slot + 1] = (double)a.y;
+                pd.px2[2 * slot] = (double)b.x;
+                pd.px2[2 * slot + 1] = (double)b.y;
+            }
         }
     }
-    if (tid == 0 && (tile == n_tiles - 1 || n_tiles == 0)) *pd.n_good = base;
+    if (fused && tid == 0 && tile == 0) ransac_reset_result(pb);
+    if (tid == 0 && (tile == n_tiles - 1 || n_tiles == 0)) {
+        *pd.n_good = base;
+        if (fused) pb.result[R_N] = base;
+    }
 }
 
 __global__ void __launch_bounds__(1024) inlier_compact_kernel(const PairDev* __restrict__ pairs)

@@ -113,7 +113,7 @@ int fill_params(sfm_gpu_ctx* ctx, RansacProb& pb, const RansacParams& rp)
 // the masks and models are on the device; the stream has been synchronised.
 int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int hyp_cap,
                  const RansacParams& rp, const int32_t* custom_table_host, std::vector<int32_t>& results,
-                 bool need_results, RansacProb* dprobs_ready = nullptr)
+                 bool need_results, RansacProb* dprobs_ready = nullptr, bool points_ready = false)
 {
     const int n_prob = (int)probs.size();
     const int m = probs[0].m;
@@ -124,7 +124,7 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         dprobs = ctx->rs_misc.as<RansacProb>();
         SFM_HIP(ctx, ctx->upload(dprobs, probs.data(), sizeof(RansacProb) * n_prob));
     }
-    {
+    if (!points_ready) {  // (the pair pipeline's ratio kernel prepares the points itself)
         ProfScope ps(ctx, "ransac_prep");
         SFM_HIP(ctx, launch_ransac_prep(s, dprobs, n_prob, cap));
     }
@@ -501,6 +501,9 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
     std::vector<RansacProb> probs(g, pl.proto);
     std::vector<int32_t> results;
     pds.assign(g, PairDev());
+    // device layout of the descriptor block: jobs | pairs | problems
+    const size_t off_pd = align_up(sizeof(KnnJob) * (size_t)g, 64);
+    const size_t off_pb = off_pd + align_up(sizeof(PairDev) * (size_t)g, 64);
     const KnnPlan plan = plan_knn(pl.nq_max, pl.nt_max, g, ctx->knn_variant);
     // a smaller (last) group may be planned with more train parts per job: size
     // the record buffer from this group's own plan
@@ -535,6 +538,7 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
         pd.n_good = ctx->mp_ngood.as<int32_t>() + 2 * i;
         pd.n_inliers = pd.n_good + 1;
         pd.host_counts = (int32_t*)res_pinned + 2 * i;
+        pd.prob = (const RansacProb*)(ctx->jobs.as<char>() + off_pb) + i;
         pd.n_query = q.n;
         pd.capacity = match_capacity;
         RansacProb& pb = probs[i];
@@ -547,8 +551,6 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
         pd.result = pb.result;
     }
     // the three descriptor arrays travel as one block: one copy on the stream
-    const size_t off_pd = align_up(sizeof(KnnJob) * (size_t)g, 64);
-    const size_t off_pb = off_pd + align_up(sizeof(PairDev) * (size_t)g, 64);
     const size_t blob_b = off_pb + sizeof(RansacProb) * (size_t)g;
     std::vector<char> blob(blob_b);
     memcpy(blob.data(), jobs.data(), sizeof(KnnJob) * (size_t)g);
@@ -592,7 +594,7 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
         ProfScope ps(ctx, "ratio_compact");
         SFM_HIP(ctx, launch_ratio_compact(s, dpds, g, pl.nq_max, params->ratio));
     }
-    int rc = ransac_batch(ctx, probs, pl.nq_max, pl.hyp_cap, pl.rp, nullptr, results, false, dprobs);
+    int rc = ransac_batch(ctx, probs, pl.nq_max, pl.hyp_cap, pl.rp, nullptr, results, false, dprobs, true);
     if (rc) return rc;
     {
         ProfScope ps(ctx, "inlier_compact");

@@ -51,6 +51,58 @@ struct RansacProb {
     int32_t cap_pad;       // plane stride of soa (even, >= cap)
 };
 
+// What RANSAC keeps of correspondence i, given its pixel coordinates in both
+// images: normalised coordinates for the essential model (x = (u-cx)/fx,
+// y = (v-cy)/fy), float32-narrowed pixels for the fundamental model, as the two
+// OpenCV front ends prepare them, plus the float32 planes the scoring filter
+// reads (blocks of four points, [block][X1 Y1 X2 Y2][4]: one 64-byte scalar load
+// brings four points with pairs of equal coordinates adjacent).
+__device__ __forceinline__ void ransac_prep_point(const RansacProb& pb, int i, double u1, double v1, double u2,
+                                                  double v2)
+{
+    double a1, b1, a2, b2;
+    if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
+        a1 = (u1 - pb.cx) / pb.fx;
+        b1 = (v1 - pb.cy) / pb.fy;
+        a2 = (u2 - pb.cx) / pb.fx;
+        b2 = (v2 - pb.cy) / pb.fy;
+    } else {
+        const float f1x = (float)u1, f1y = (float)v1, f2x = (float)u2, f2y = (float)v2;
+        pb.f1[2 * i] = f1x;
+        pb.f1[2 * i + 1] = f1y;
+        pb.f2[2 * i] = f2x;
+        pb.f2[2 * i + 1] = f2y;
+        // the same values widened again: what the error function computes on
+        a1 = (double)f1x;
+        b1 = (double)f1y;
+        a2 = (double)f2x;
+        b2 = (double)f2y;
+    }
+    pb.x1[2 * i] = a1;
+    pb.x1[2 * i + 1] = b1;
+    pb.x2[2 * i] = a2;
+    pb.x2[2 * i + 1] = b2;
+    float* blk = pb.soa + (size_t)(i >> 2) * 16 + (i & 3);
+    blk[0] = (float)a1;
+    blk[4] = (float)b1;
+    blk[8] = (float)a2;
+    blk[12] = (float)b2;
+}
+
+// Clears a problem's result block (every slot but the point count R_N).
+__device__ __forceinline__ void ransac_reset_result(const RansacProb& pb)
+{
+    pb.result[R_OK] = 0;
+    pb.result[R_HYP] = -1;
+    pb.result[R_Q] = -1;
+    pb.result[R_NINL] = 0;
+    pb.result[R_ITERS] = 0;
+    pb.result[R_VALID] = 0;
+    pb.result[R_DIRECT] = 0;
+    pb.result[R_NLIST] = 0;
+    pb.result[R_MAXABS] = 0;
+}
+
 hipError_t launch_ransac_prep(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
 hipError_t launch_ransac_table(hipStream_t s, const RansacProb* probs, int n_prob, int row0, int nrows);
 hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int n_prob, int nrows);
@@ -81,6 +133,7 @@ struct PairDev {
     sfm_gpu_dmatch* inliers;    // [capacity] or null
     int32_t* n_inliers;         // [1]
     int32_t* host_counts;       // [2] pinned host memory: (n_good, n_inliers) for the caller, or null
+    const RansacProb* prob;     // the pair's RANSAC problem: the ratio kernel prepares its points itself; or null
     int32_t n_query;
     int32_t capacity;
 };

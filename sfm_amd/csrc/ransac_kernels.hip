@@ -944,53 +944,19 @@ __device__ __forceinline__ int symepi_inlier(const double* F, float fx1, float f
 
 // ---- kernels -------------------------------------------------------------------
 
-// Normalises pixel coordinates for the essential model (x = (u-cx)/fx,
-// y = (v-cy)/fy) or narrows them to float32 for the fundamental model, as the
-// two OpenCV front ends do before RANSAC.  Also clears the per-problem result.
+// Prepares the points of each problem from its pixel coordinates
+// (ransac_prep_point) and clears the per-problem result.
 __global__ void __launch_bounds__(256) ransac_prep_kernel(const RansacProb* __restrict__ probs)
 {
     const RansacProb pb = probs[blockIdx.y];
     const int n = *pb.n_ptr;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) {
-        pb.result[R_OK] = 0;
-        pb.result[R_HYP] = -1;
-        pb.result[R_Q] = -1;
-        pb.result[R_NINL] = 0;
-        pb.result[R_ITERS] = 0;
-        pb.result[R_VALID] = 0;
-        pb.result[R_DIRECT] = 0;
+        ransac_reset_result(pb);
         pb.result[R_N] = n;
-        pb.result[R_NLIST] = 0;
-        pb.result[R_MAXABS] = 0;
     }
     if (i >= n) return;
-    if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
-        pb.x1[2 * i] = (pb.px1[2 * i] - pb.cx) / pb.fx;
-        pb.x1[2 * i + 1] = (pb.px1[2 * i + 1] - pb.cy) / pb.fy;
-        pb.x2[2 * i] = (pb.px2[2 * i] - pb.cx) / pb.fx;
-        pb.x2[2 * i + 1] = (pb.px2[2 * i + 1] - pb.cy) / pb.fy;
-    } else {
-        pb.f1[2 * i] = (float)pb.px1[2 * i];
-        pb.f1[2 * i + 1] = (float)pb.px1[2 * i + 1];
-        pb.f2[2 * i] = (float)pb.px2[2 * i];
-        pb.f2[2 * i + 1] = (float)pb.px2[2 * i + 1];
-        // the same values widened again: what the error function computes on
-        pb.x1[2 * i] = (double)pb.f1[2 * i];
-        pb.x1[2 * i + 1] = (double)pb.f1[2 * i + 1];
-        pb.x2[2 * i] = (double)pb.f2[2 * i];
-        pb.x2[2 * i + 1] = (double)pb.f2[2 * i + 1];
-    }
-    // float32 planes X1, Y1, X2, Y2 of the coordinates the error function works
-    // on (exact for the fundamental model, rounded for the essential one): the
-    // scoring kernel's single-precision filter reads pairs of points from them
-    // layout: blocks of four points, [block][X1 Y1 X2 Y2][4]: one 64-byte scalar
-    // load brings four points with pairs of equal coordinates adjacent
-    float* blk = pb.soa + (size_t)(i >> 2) * 16 + (i & 3);
-    blk[0] = (float)pb.x1[2 * i];
-    blk[4] = (float)pb.x1[2 * i + 1];
-    blk[8] = (float)pb.x2[2 * i];
-    blk[12] = (float)pb.x2[2 * i + 1];
+    ransac_prep_point(pb, i, pb.px1[2 * i], pb.px1[2 * i + 1], pb.px2[2 * i], pb.px2[2 * i + 1]);
 }
 
 struct CvRng {
