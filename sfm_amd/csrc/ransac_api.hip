@@ -113,7 +113,8 @@ int fill_params(sfm_gpu_ctx* ctx, RansacProb& pb, const RansacParams& rp)
 // the masks and models are on the device; the stream has been synchronised.
 int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int hyp_cap,
                  const RansacParams& rp, const int32_t* custom_table_host, std::vector<int32_t>& results,
-                 bool need_results, RansacProb* dprobs_ready = nullptr, bool points_ready = false)
+                 bool need_results, RansacProb* dprobs_ready = nullptr, bool points_ready = false,
+                 const PairDev* dpairs = nullptr, bool* pairs_done = nullptr)
 {
     const int n_prob = (int)probs.size();
     const int m = probs[0].m;
@@ -178,7 +179,8 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         {
             // winner, then its mask and model copy, by the same workgroup per problem
             ProfScope ps(ctx, "ransac_select");
-            SFM_HIP(ctx, launch_ransac_select(s, dprobs, n_prob, nh));
+            SFM_HIP(ctx, launch_ransac_select(s, dprobs, n_prob, nh, dpairs));
+            if (pairs_done) *pairs_done = dpairs != nullptr;
         }
         // the whole fixed-count path runs without the host; callers that keep
         // working on the device need not wait here
@@ -594,9 +596,11 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
         ProfScope ps(ctx, "ratio_compact");
         SFM_HIP(ctx, launch_ratio_compact(s, dpds, g, pl.nq_max, params->ratio));
     }
-    int rc = ransac_batch(ctx, probs, pl.nq_max, pl.hyp_cap, pl.rp, nullptr, results, false, dprobs, true);
+    bool pairs_done = false;  // fixed-count mode: the selection kernel has gathered the inliers too
+    int rc = ransac_batch(ctx, probs, pl.nq_max, pl.hyp_cap, pl.rp, nullptr, results, false, dprobs, true, dpds,
+                          &pairs_done);
     if (rc) return rc;
-    {
+    if (!pairs_done) {
         ProfScope ps(ctx, "inlier_compact");
         SFM_HIP(ctx, launch_inlier_compact(s, dpds, g));
     }

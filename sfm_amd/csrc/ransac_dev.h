@@ -115,7 +115,6 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
                                int n_hyp, int prune, int mid);
 void set_ransac_score_filter(int on);
 void set_ransac_score_prune(int on);
-hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp);
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
 
 // One image pair between the k-NN output and RANSAC (pair_kernels.hip).
@@ -143,5 +142,9 @@ hipError_t launch_ratio_compact(hipStream_t s, const PairDev* pairs, int n_pairs
 hipError_t launch_upload_block(hipStream_t s, void* dst, const void* src_pinned, size_t bytes, int32_t* redo,
                                size_t redo_stride, int n_jobs);
 hipError_t launch_inlier_compact(hipStream_t s, const PairDev* pairs, int n_pairs);
+// pairs != null: the kernel also gathers each pair's inlier matches and reports
+// its two counts (what launch_inlier_compact does as a launch of its own)
+hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp,
+                                const PairDev* pairs);
 
 }  // namespace sfm

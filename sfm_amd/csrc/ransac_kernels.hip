@@ -1747,14 +1747,32 @@ __global__ void __launch_bounds__(1024) ransac_prune_kernel(const RansacProb* __
 // `if (good > max(best, m-1))` ends with.
 // The same workgroup then writes the winner's inlier mask and a copy of the
 // model (what ransac_mask_kernel does for the adaptive mode).
-__global__ void __launch_bounds__(1024) ransac_select_kernel(const RansacProb* __restrict__ probs, int n_hyp)
+// With `pairs` (the pair pipeline) it also gathers the inlier matches
+// (main.cpp:225-231) and hands the pair's two counts to the host, which saves a
+// launch of its own for that.
+__global__ void __launch_bounds__(1024) ransac_select_kernel(const RansacProb* __restrict__ probs, int n_hyp,
+                                                             const PairDev* __restrict__ pairs)
 {
     __shared__ unsigned long long sh[16];
     __shared__ int s_sel[4];  // ok, hypothesis, model, direct
+    __shared__ int s_wsum[16];
     const RansacProb pb = probs[blockIdx.x];
     const int n = *pb.n_ptr;
     const int tid = threadIdx.x;
-    if (n < pb.m) return;
+    PairDev pd;
+    if (pairs) pd = pairs[blockIdx.x];
+    auto report = [&](int n_inl) {  // one thread
+        if (!pairs) return;
+        *pd.n_inliers = n_inl;
+        if (pd.host_counts) {
+            pd.host_counts[0] = n;
+            pd.host_counts[1] = n_inl;
+        }
+    };
+    if (n < pb.m) {
+        if (tid == 0) report(0);
+        return;
+    }
     const int valid = min(n_hyp, pb.result[R_VALID]);
     unsigned long long best = 0;
     for (int e = tid; e < valid * 10; e += 1024) {
@@ -1800,26 +1818,51 @@ __global__ void __launch_bounds__(1024) ransac_select_kernel(const RansacProb* _
         s_sel[3] = direct;
     }
     __syncthreads();
-    if (!s_sel[0]) return;  // mask left untouched when no model was found
+    if (!s_sel[0]) {  // mask left untouched when no model was found
+        if (tid == 0) report(0);
+        return;
+    }
     const double* Mg = pb.models + (size_t)s_sel[1] * 90 + s_sel[2] * 9;
     double M[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) M[i] = Mg[i];
     if (tid < 9) pb.model_out[tid] = M[tid];
     const bool direct = s_sel[3] != 0;
-    for (int i = tid; i < n; i += 1024) {
-        int f;
-        if (direct) {
-            f = 1;
-        } else if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
-            f = sampson_inlier(M, pb.x1[2 * i], pb.x1[2 * i + 1], pb.x2[2 * i], pb.x2[2 * i + 1], pb.tf, pb.tlo,
-                               pb.thi);
-        } else {
-            f = symepi_inlier(M, pb.f1[2 * i], pb.f1[2 * i + 1], pb.f2[2 * i], pb.f2[2 * i + 1], pb.tf, pb.tlo,
-                              pb.thi);
+    const int lane = tid & 63, wv = tid >> 6;
+    int running = 0;  // inliers in the tiles before this one (the same in every thread)
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        int f = 0;
+        if (i < n) {
+            if (direct) {
+                f = 1;
+            } else if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
+                f = sampson_inlier(M, pb.x1[2 * i], pb.x1[2 * i + 1], pb.x2[2 * i], pb.x2[2 * i + 1], pb.tf, pb.tlo,
+                                   pb.thi);
+            } else {
+                f = symepi_inlier(M, pb.f1[2 * i], pb.f1[2 * i + 1], pb.f2[2 * i], pb.f2[2 * i + 1], pb.tf, pb.tlo,
+                                  pb.thi);
+            }
+            pb.mask[i] = (uint8_t)f;
         }
-        pb.mask[i] = (uint8_t)f;
+        if (pairs) {
+            // order-preserving compaction of this tile's inlier matches
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(f != 0);
+            if (lane == 0) s_wsum[wv] = __popcll(m);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < 16; ++w) {
+                const int c = s_wsum[w];
+                if (w < wv) before += c;
+                total += c;
+            }
+            const int slot = running + before + __popcll(m & ((1ull << lane) - 1ull));
+            if (f && pd.inliers && slot < pd.capacity) pd.inliers[slot] = pd.good[i];
+            running += total;
+            __syncthreads();
+        }
     }
+    if (pairs && tid == 0) report(running);
 }
 
 // Inlier mask of the selected model (result[R_HYP], result[R_Q]) and a copy of
@@ -1954,9 +1997,9 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     }
     return hipGetLastError();
 }
-hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp)
+hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp, const PairDev* pairs)
 {
-    hipLaunchKernelGGL(ransac_select_kernel, dim3(n_prob), dim3(1024), 0, s, probs, n_hyp);
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(n_prob), dim3(1024), 0, s, probs, n_hyp, pairs);
     return hipGetLastError();
 }
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap)
