@@ -148,13 +148,15 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
                                         hipMemcpyHostToDevice, s));
             const int32_t valid = nh;
             SFM_HIP(ctx, hipMemcpyAsync(probs[0].result + R_VALID, &valid, 4, hipMemcpyHostToDevice, s));
-        } else {
+        } else if (rp.model != SFM_GPU_MODEL_FUNDAMENTAL) {
             ProfScope ps(ctx, "ransac_table");
             SFM_HIP(ctx, launch_ransac_table_fixed(s, dprobs, n_prob, nh));
         }
         {
+            // the seven-point solver draws its own rows unless the caller brought a table
+            const int gen = (!custom_table_host && rp.model == SFM_GPU_MODEL_FUNDAMENTAL) ? nh : 0;
             ProfScope ps(ctx, "ransac_solve");
-            SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, rp.model, 0, nh));
+            SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, rp.model, 0, nh, gen));
         }
         {
             // First stage of the scoring: it has to outnumber the outliers for the

@@ -106,7 +106,10 @@ __device__ __forceinline__ void ransac_reset_result(const RansacProb& pb)
 hipError_t launch_ransac_prep(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
 hipError_t launch_ransac_table(hipStream_t s, const RansacProb* probs, int n_prob, int row0, int nrows);
 hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int n_prob, int nrows);
-hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp);
+// gen_rows > 0 (fundamental model only, hyp0 = 0): the solver draws the fixed-count
+// sample rows itself instead of reading a table made by launch_ransac_table_fixed
+hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp,
+                               int gen_rows = 0);
 // prune > 0: every model is first scored on the first `prune` points, then the
 // models that provably cannot reach the best count are dropped (their counts
 // stay partial) and the rest go on; the selected model, its count and the mask

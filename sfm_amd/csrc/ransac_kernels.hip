@@ -1200,7 +1200,13 @@ __global__ void __launch_bounds__(64) ransac_solve_kernel(const RansacProb* __re
 // that follows needs none and runs at full occupancy.  The pencil travels
 // through the hypothesis' own slot of the models buffer; nmodels = -1 marks a
 // hypothesis whose pencil is waiting there.
-__global__ void __launch_bounds__(64) ransac_solve7_kernel(const RansacProb* __restrict__ probs, int hyp0, int n_hyp)
+// gen_rows > 0 (fixed-count mode, hyp0 = 0): the kernel draws the sample rows
+// itself, exactly as ransac_table_fixed_kernel would (the points a row's
+// collinearity check gathers are the ones the solver needs next), stores them
+// in the table for the test hooks and sets the row count; gen_rows = 0: the
+// rows are read from the table.
+__global__ void __launch_bounds__(64) ransac_solve7_kernel(const RansacProb* __restrict__ probs, int hyp0, int n_hyp,
+                                                           int gen_rows)
 {
     __shared__ double sA[63 * 64];
     const RansacProb pb = probs[blockIdx.y];
@@ -1208,24 +1214,13 @@ __global__ void __launch_bounds__(64) ransac_solve7_kernel(const RansacProb* __r
     const int hyp = hyp0 + blockIdx.x * 64 + lane;
     const bool in_range = hyp < hyp0 + n_hyp;
     const int n = *pb.n_ptr;
-    bool active = in_range && n >= 7 && hyp < pb.result[R_VALID];
+    const int valid = gen_rows > 0 ? (n == 7 ? 1 : gen_rows) : pb.result[R_VALID];
+    bool active = in_range && n >= 7 && hyp < valid;
     int idx[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) idx[k] = 0;
-    if (active) {
-        const int* row = pb.table + (size_t)hyp * 7;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) idx[k] = row[k];
-        if (idx[0] < 0) {  // the row could not be drawn
-            active = false;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) idx[k] = 0;
-        }
-    }
-    // inactive lanes run on seven copies of point 0 (rejected at the first
-    // zero pivot) and drop the result
     float m1[14], m2[14];
-    if (n > 0) {
+    auto gather = [&]() {
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const float2 u = ((const float2*)pb.f1)[idx[k]];
@@ -1233,6 +1228,52 @@ __global__ void __launch_bounds__(64) ransac_solve7_kernel(const RansacProb* __r
             m1[2 * k] = u.x; m1[2 * k + 1] = u.y;
             m2[2 * k] = v.x; m2[2 * k + 1] = v.y;
         }
+    };
+    if (gen_rows > 0) {
+        if (n >= 7 && blockIdx.x == 0 && lane == 0) {
+            pb.result[R_VALID] = valid;
+            if (n == 7) pb.result[R_DIRECT] = 1;
+        }
+        if (active) {
+            if (n == 7) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) idx[k] = k;
+                gather();
+            } else {
+                bool ok = false;
+                for (unsigned u = 0; u < 64 && !ok; ++u) {
+                    for (int i = 0; i < 7; ++i) {
+                        for (unsigned t = 0;; ++t) {
+                            const int v = fixed_draw(n, (unsigned)hyp, u, (unsigned)i, t);
+                            int j = 0;
+                            for (; j < i; ++j)
+                                if (idx[j] == v) break;
+                            if (j == i) { idx[i] = v; break; }
+                        }
+                    }
+                    gather();
+                    ok = !(have_collinear(m1, 7) || have_collinear(m2, 7));
+                }
+                if (!ok) idx[0] = -1;
+            }
+            int* row = pb.table + (size_t)hyp * 7;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) row[k] = idx[k];
+        }
+    } else if (active) {
+        const int* row = pb.table + (size_t)hyp * 7;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) idx[k] = row[k];
+    }
+    if (active && idx[0] < 0) active = false;  // the row could not be drawn
+    // inactive lanes run on seven copies of point 0 (rejected at the first
+    // zero pivot) and drop the result
+    if (!active) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) idx[k] = 0;
+    }
+    if (n > 0) {
+        if (!(gen_rows > 0 && active)) gather();
     } else {
 #pragma unroll
         for (int k = 0; k < 14; ++k) m1[k] = m2[k] = 0.f;
@@ -1916,11 +1957,13 @@ hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int
     hipLaunchKernelGGL(ransac_table_fixed_kernel, dim3((nrows + 255) / 256, n_prob), dim3(256), 0, s, probs, nrows);
     return hipGetLastError();
 }
-hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp)
+hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp,
+                               int gen_rows)
 {
     if (model == SFM_GPU_MODEL_FUNDAMENTAL)
     {
-        hipLaunchKernelGGL(ransac_solve7_kernel, dim3((n_hyp + 63) / 64, n_prob), dim3(64), 0, s, probs, hyp0, n_hyp);
+        hipLaunchKernelGGL(ransac_solve7_kernel, dim3((n_hyp + 63) / 64, n_prob), dim3(64), 0, s, probs, hyp0, n_hyp,
+                           gen_rows);
         const int per_wg = ROOTS7_WAVES * 21;
         hipLaunchKernelGGL(ransac_roots7_kernel, dim3((n_hyp + per_wg - 1) / per_wg, n_prob), dim3(ROOTS7_WAVES * 64),
                            0, s, probs, hyp0, n_hyp);
