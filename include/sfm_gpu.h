@@ -244,6 +244,28 @@ int sfm_gpu_knn_match_images(sfm_gpu_ctx* ctx, const sfm_gpu_image* query,
                              const sfm_gpu_image* train, int k, sfm_gpu_dmatch* matches,
                              int32_t* counts, int out_on_device);
 
+/*
+ * sfm_gpu_knn_match_images with device outputs, for callers that cannot
+ * allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  No counterpart in the reference.  The call
+ * allocates nothing and copies nothing: the sweep records, the list of queries
+ * for the float-ranked pass and the job descriptor live in a static device
+ * array that is part of the library's code object (8.2 MiB per GPU, held until
+ * the process ends), and the call only enqueues kernels on the context's
+ * stream.
+ *
+ *   matches_dev, counts_dev   device pointers, n_query*k records / n_query
+ *                             counts, as sfm_gpu_knn_match_images writes them
+ * Limits: at most 32768 query rows and 524288 sweep records (train parts x
+ * query rows padded to 1024) -- every size up to 32768 x 262143 fits;
+ * SFM_GPU_ERR_CAPACITY beyond.  All calls on one GPU share that GPU's array:
+ * two such calls that overlap in time on one GPU (different streams or
+ * contexts) race; calls on one stream are ordered and safe.
+ */
+int sfm_gpu_knn_match_images_noalloc(sfm_gpu_ctx* ctx, const sfm_gpu_image* query,
+                                     const sfm_gpu_image* train, int k,
+                                     sfm_gpu_dmatch* matches_dev, int32_t* counts_dev);
+
 /* Parameters of one match() iteration (main.cpp:181-231). */
 typedef struct sfm_gpu_match_params {
     double ratio;        /* 0.7 at main.cpp:189                                */

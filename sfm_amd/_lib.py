@@ -81,6 +81,7 @@ def lib():
     L.sfm_gpu_image_wrap.argtypes = [vp, vp, c.c_int, c.c_int, c.POINTER(vp)]
     L.sfm_gpu_check_inputs.argtypes = [vp]
     L.sfm_gpu_knn_match_images.argtypes = [vp, vp, vp, c.c_int, vp, vp, c.c_int]
+    L.sfm_gpu_knn_match_images_noalloc.argtypes = [vp, vp, vp, c.c_int, vp, vp]
     L.sfm_gpu_match_pairs.argtypes = [vp, vp, c.c_int, vp, c.c_int, c.POINTER(MatchParams), vp, vp, vp,
                                       c.c_int]
     L.sfm_gpu_match_pairs_begin.argtypes = [vp, vp, c.c_int, vp, c.c_int, c.POINTER(MatchParams)]

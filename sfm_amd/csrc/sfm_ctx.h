@@ -123,6 +123,9 @@ struct sfm_gpu_ctx {
     bool own_stream = false;
     std::string err;
     int knn_variant = -1;  // -1: planner decides
+    // this device's copy of the library's static working memory (the calls that
+    // must not allocate work there); resolved once per device at creation
+    void* static_scratch = nullptr;
 
     sfm::DevBuf raw_q, raw_t;
     sfm::ImageStore tmp_q, tmp_t;
@@ -221,7 +224,7 @@ struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
     ProfScope(sfm_gpu_ctx* ctx, const char* name) : c(ctx)
     {
-        if (!c->profiling) return;
+        if (!c || !c->profiling) return;
         if (!c->profile_only.empty() && c->profile_only != name) return;
         t = &c->timers[name];
         t->name = name;

@@ -101,6 +101,62 @@ int prepare_image(sfm_gpu_ctx* ctx, ImageStore& st, DevBuf& raw, const void* des
     return SFM_GPU_OK;
 }
 
+// Stores one k-NN job descriptor in device memory and clears the counter of the
+// float-ranked pass, so that a call needs neither a copy nor a fill.
+__global__ void store_knn_job_kernel(KnnJob job, KnnJob* dst, int32_t* redo_count)
+{
+    if (threadIdx.x == 0) {
+        *dst = job;
+        *redo_count = 0;
+    }
+}
+
+// Device memory a k-NN call works in besides its inputs and outputs.
+struct KnnWorkspace {
+    uint4* partial;   // [n_splits][q.rows_alloc] sweep records
+    int32_t* redo;    // [1 + n_query]
+    KnnJob* job;
+};
+
+KnnJob make_knn_job(const ImageDev& q, const ImageDev& t, const KnnWorkspace& ws, sfm_gpu_dmatch* out_dev,
+                    int32_t* cnt_dev)
+{
+    KnnJob job;
+    job.q_desc = q.desc;
+    job.t_desc = t.desc;
+    job.t_cin = t.cin;
+    job.q_qn = q.qn;
+    job.t_qn = t.qn;
+    job.partial = ws.partial;
+    job.out = out_dev;
+    job.counts = cnt_dev;
+    job.redo = ws.redo;
+    job.n_query = q.n;
+    job.n_train = t.n;
+    job.q_rows_alloc = q.rows_alloc;
+    job.t_chunks = t.n > 0 ? (t.n + CHUNK - 1) / CHUNK : 0;
+    return job;
+}
+
+// sweep -> neighbour extraction -> float-ranked pass for one job already stored at ws.job
+int enqueue_knn(sfm_gpu_ctx* ctx, const ImageDev& q, const KnnWorkspace& ws, const KnnPlan& plan, int k,
+                bool timers)
+{
+    {
+        ProfScope ps(timers ? ctx : nullptr, "knn2_mfma");
+        SFM_HIP(ctx, launch_knn2(ctx->stream, ws.job, 1, q.rows_alloc, plan));
+    }
+    {
+        ProfScope ps(timers ? ctx : nullptr, "knn_finalize");
+        SFM_HIP(ctx, launch_knn_finalize(ctx->stream, ws.job, 1, q.n, plan.n_splits, k, plan.group_mode, 0.0));
+    }
+    {
+        ProfScope ps(timers ? ctx : nullptr, "knn_redo");
+        SFM_HIP(ctx, launch_knn_redo(ctx->stream, ws.job, 1, plan.n_splits, k, 0.0));
+    }
+    return SFM_GPU_OK;
+}
+
 int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
                   sfm_gpu_dmatch* matches, int32_t* counts, bool out_on_device)
 {
@@ -118,34 +174,12 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
         out_dev = ctx->out.as<sfm_gpu_dmatch>();
         cnt_dev = ctx->counts.as<int32_t>();
     }
-    KnnJob job;
-    job.q_desc = q.desc;
-    job.t_desc = t.desc;
-    job.t_cin = t.cin;
-    job.q_qn = q.qn;
-    job.t_qn = t.qn;
-    job.partial = ctx->partial.as<uint4>();
-    job.out = out_dev;
-    job.counts = cnt_dev;
-    job.redo = ctx->redo.as<int32_t>();
-    job.n_query = nq;
-    job.n_train = nt;
-    job.q_rows_alloc = q.rows_alloc;
-    job.t_chunks = nt > 0 ? (nt + CHUNK - 1) / CHUNK : 0;
-    SFM_HIP(ctx, hipMemcpyAsync(ctx->jobs.p, &job, sizeof(job), hipMemcpyHostToDevice, ctx->stream));
-    SFM_HIP(ctx, hipMemsetAsync(ctx->redo.p, 0, 4, ctx->stream));
-    {
-        ProfScope ps(ctx, "knn2_mfma");
-        SFM_HIP(ctx, launch_knn2(ctx->stream, ctx->jobs.as<KnnJob>(), 1, q.rows_alloc, plan));
-    }
-    {
-        ProfScope ps(ctx, "knn_finalize");
-        SFM_HIP(ctx, launch_knn_finalize(ctx->stream, ctx->jobs.as<KnnJob>(), 1, nq, plan.n_splits, k, plan.group_mode, 0.0));
-    }
-    {
-        ProfScope ps(ctx, "knn_redo");
-        SFM_HIP(ctx, launch_knn_redo(ctx->stream, ctx->jobs.as<KnnJob>(), 1, plan.n_splits, k, 0.0));
-    }
+    const KnnWorkspace ws = {ctx->partial.as<uint4>(), ctx->redo.as<int32_t>(), ctx->jobs.as<KnnJob>()};
+    const KnnJob job = make_knn_job(q, t, ws, out_dev, cnt_dev);
+    SFM_HIP(ctx, hipMemcpyAsync(ws.job, &job, sizeof(job), hipMemcpyHostToDevice, ctx->stream));
+    SFM_HIP(ctx, hipMemsetAsync(ws.redo, 0, 4, ctx->stream));
+    const int rc = enqueue_knn(ctx, q, ws, plan, k, true);
+    if (rc) return rc;
     if (!out_on_device) {
         SFM_HIP(ctx, hipMemcpyAsync(matches, out_dev, (size_t)nq * k * sizeof(sfm_gpu_dmatch),
                                     hipMemcpyDeviceToHost, ctx->stream));
@@ -153,6 +187,36 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
         SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return SFM_GPU_OK;
+}
+
+// ---- working memory of sfm_gpu_knn_match_images_noalloc --------------------
+// One array per GPU the library runs on, part of the code object, so the entry
+// point never allocates.  Layout: sweep records | redo list | job descriptor.
+constexpr size_t NOALLOC_MAX_RECORDS = 524288;  // uint4 records: n_splits * padded query rows
+constexpr int NOALLOC_MAX_QUERY = 32768;
+constexpr size_t NOALLOC_REDO_OFF = NOALLOC_MAX_RECORDS * sizeof(uint4);
+constexpr size_t NOALLOC_JOB_OFF = NOALLOC_REDO_OFF + ((size_t)NOALLOC_MAX_QUERY + 64) * 4;
+constexpr size_t NOALLOC_BYTES = NOALLOC_JOB_OFF + 256;
+static_assert(sizeof(KnnJob) <= 256, "job descriptor must fit its slot");
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
+// Address of this device's copy of `scratch` (the array's name is only a handle
+// on the host side; every GPU has its own copy at its own address).  The
+// caller has made `device` current.
+constexpr int MAX_DEVICES = 64;
+void* g_scratch_ptr[MAX_DEVICES] = {};
+hipError_t resolve_scratch(int device, void** out)
+{
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
 }
 
 }  // namespace
@@ -168,7 +232,14 @@ int sfm_gpu_create(int device_id, void* hip_stream, sfm_gpu_ctx** out)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev)
         return SFM_GPU_ERR_HIP;
+    int prev_dev = -1;
+    if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
     if (hipSetDevice(device_id) != hipSuccess) return SFM_GPU_ERR_HIP;
+    // the caller's current device is left as it was
+    struct Restore {
+        int d;
+        ~Restore() { if (d >= 0) (void)hipSetDevice(d); }
+    } restore{prev_dev};
     sfm_gpu_ctx* c = new (std::nothrow) sfm_gpu_ctx();
     if (!c) return SFM_GPU_ERR_NOMEM;
     c->device = device_id;
@@ -181,7 +252,10 @@ int sfm_gpu_create(int device_id, void* hip_stream, sfm_gpu_ctx** out)
         }
         c->own_stream = true;
     }
-    if (c->flags.reserve(64) != hipSuccess || hipMemsetAsync(c->flags.p, 0, 64, c->stream) != hipSuccess) {
+    if (c->flags.reserve(64) != hipSuccess || hipMemsetAsync(c->flags.p, 0, 64, c->stream) != hipSuccess ||
+        resolve_scratch(device_id, &c->static_scratch) != hipSuccess) {
+        c->flags.release();
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return SFM_GPU_ERR_HIP;
     }
@@ -334,6 +408,35 @@ int sfm_gpu_knn_match_images(sfm_gpu_ctx* ctx, const sfm_gpu_image* query, const
     if (query->d.n > 0 && (!matches || !counts)) return ctx->fail(SFM_GPU_ERR_ARG, "null output pointer");
     SFM_HIP(ctx, hipSetDevice(ctx->device));
     return knn_on_images(ctx, query->d, train->d, k, matches, counts, out_on_device != 0);
+}
+
+int sfm_gpu_knn_match_images_noalloc(sfm_gpu_ctx* ctx, const sfm_gpu_image* query, const sfm_gpu_image* train,
+                                     int k, sfm_gpu_dmatch* matches_dev, int32_t* counts_dev)
+{
+    if (!ctx || !query || !train) return SFM_GPU_ERR_ARG;
+    int rc = check_knn_args(ctx, query->d.n, train->d.n, DIM, SFM_GPU_DESC_U8, k);
+    if (rc) return rc;
+    const ImageDev& q = query->d;
+    const ImageDev& t = train->d;
+    if (q.n == 0) return SFM_GPU_OK;
+    if (!matches_dev || !counts_dev) return ctx->fail(SFM_GPU_ERR_ARG, "null output pointer");
+    if (!ctx->static_scratch) return ctx->fail(SFM_GPU_ERR_HIP, "static working memory was not resolved");
+    const KnnPlan plan = plan_knn(q.n, t.n, 1, -1);
+    const size_t records = (size_t)plan.n_splits * q.rows_alloc;
+    if (q.n > NOALLOC_MAX_QUERY || records > NOALLOC_MAX_RECORDS)
+        return ctx->fail(SFM_GPU_ERR_CAPACITY,
+                         "sfm_gpu_knn_match_images_noalloc: %d query rows x %d train parts = %zu records exceed "
+                         "the static working memory (at most %d query rows and %zu records)",
+                         q.n, plan.n_splits, records, NOALLOC_MAX_QUERY, NOALLOC_MAX_RECORDS);
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned char* base = (unsigned char*)ctx->static_scratch;
+    const KnnWorkspace ws = {(uint4*)base, (int32_t*)(base + NOALLOC_REDO_OFF), (KnnJob*)(base + NOALLOC_JOB_OFF)};
+    const KnnJob job = make_knn_job(q, t, ws, matches_dev, counts_dev);
+    // the job descriptor and the cleared redo counter reach the device as kernel
+    // arguments: no copy, no fill, nothing staged
+    hipLaunchKernelGGL(store_knn_job_kernel, dim3(1), dim3(64), 0, ctx->stream, job, ws.job, ws.redo);
+    SFM_HIP(ctx, hipGetLastError());
+    return enqueue_knn(ctx, q, ws, plan, k, false);
 }
 
 size_t sfm_gpu_image_packed_bytes(int n) { return n < 0 ? 0 : image_block_bytes(n); }
