@@ -14,7 +14,12 @@ extern "C" {
 
 /* Forces the shape of the distance kernel (-1: planner decides): 0..3 = 32x32x32
  * MFMAs with {4x4, 2x4, 2x8, 4x8} {query blocks per wave x waves}, 4 = 16x16x64
- * MFMAs; + 16*a selects a timing ablation a (wrong results). */
+ * MFMAs.  Every shape gives the same (exact) results.  The timing build of the
+ * library (libsfm_gpu_timing.so, never the one a host links) also takes
+ * shape + 16*a, which switches parts of the kernel off for timing and gives WRONG
+ * results: a = bit 0 no digest of the accumulators | bit 1 no DMA of further
+ * stages | bit 2 no stage barrier; the default build answers
+ * SFM_GPU_ERR_UNSUPPORTED. */
 int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* ctx, int variant);
 
 /* Number of queries that the last k-NN call on this context (its first job)
@@ -42,22 +47,21 @@ int sfm_gpu_debug_ransac_dump(sfm_gpu_ctx* ctx, int n_hyp, int32_t* table, int32
  * differs from the correctly rounded value the match records carry. */
 int sfm_gpu_debug_sqrt_probe(sfm_gpu_ctx* ctx, int32_t* mismatches);
 
-/* 0: the RANSAC scoring kernel evaluates every (model, point) pair in double
- * precision only; 1 (default): a float32 filter with a rigorous error bound
- * settles the clear cases first.  Both give identical counts; the switch lets
- * tests prove it.  2 and 3 are timing experiments with WRONG counts (2: tests
- * the filter cannot settle are dropped; 3: also no point loads inside the
- * loop).  Process-wide. */
-int sfm_gpu_debug_set_score_filter(int on);
+/* Per context.  0: the RANSAC scoring kernel evaluates every (model, point) pair
+ * in double precision only; 1 (default): a float32 filter with a rigorous error
+ * bound settles the clear cases first.  Both give identical counts; the switch
+ * lets tests prove it.  (The timing build also takes 2 and 3, experiments with
+ * WRONG counts: 2 drops the tests the filter cannot settle, 3 also the point
+ * loads inside the loop; SFM_GPU_ERR_UNSUPPORTED in the default build.) */
+int sfm_gpu_debug_set_score_filter(sfm_gpu_ctx* ctx, int on);
 
-/* Fixed-count RANSAC scores its candidate models in stages over the points and,
- * between stages, drops the models that provably cannot reach the best count
- * (their entries in the dumped counts stay partial, never above the true
- * count).  0 switches the pruning off so that every dumped count is complete;
- * 1 (default) on; 2 on, but never more than one cut (timing comparisons).  The
- * selected model, its inlier count and the mask are the same either way.
- * Process-wide. */
-int sfm_gpu_debug_set_score_prune(int on);
+/* Per context.  Fixed-count RANSAC scores its candidate models in stages over
+ * the points and, between stages, drops the models that provably cannot reach
+ * the best count (their entries in the dumped counts stay partial, never above
+ * the true count).  0 switches the pruning off so that every dumped count is
+ * complete; 1 (default) on; 2 on, but never more than one cut.  The selected
+ * model, its inlier count and the mask are the same in every mode. */
+int sfm_gpu_debug_set_score_prune(sfm_gpu_ctx* ctx, int on);
 
 /* Vote counts of the four pose candidates in the last sfm_gpu_recover_pose call
  * on this context, in the order (R1,t) (R2,t) (R1,-t) (R2,-t). */

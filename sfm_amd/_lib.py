@@ -10,6 +10,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsfm_gpu.so")
+# the same sources built with the kernels' timing ablations (bench.py's ceiling
+# measurement and the profiling scripts only; never the product path)
+TIMING_LIB_PATH = os.path.join(_HERE, "libsfm_gpu_timing.so")
 
 DMATCH_DTYPE = np.dtype(
     [("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")]
@@ -43,17 +46,30 @@ class SfmGpuError(RuntimeError):
 
 
 _lib = None
+_timing_lib = None
 
 
 def lib():
     """Loads libsfm_gpu.so; raises if it has not been built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+def timing_lib():
+    """Loads libsfm_gpu_timing.so (kernels with their timing ablations)."""
+    global _timing_lib
+    if _timing_lib is None:
+        _timing_lib = _load(TIMING_LIB_PATH)
+    return _timing_lib
+
+
+def _load(path):
+    if not os.path.exists(path):
         raise RuntimeError(
-            "%s not found: build it with `python -m sfm_amd.build` (hipcc, gfx950)" % LIB_PATH)
-    L = ctypes.CDLL(LIB_PATH)
+            "%s not found: build it with `python -m sfm_amd.build` (hipcc, gfx950)" % path)
+    L = ctypes.CDLL(path)
     c = ctypes
     vp = c.c_void_p
     L.sfm_gpu_version.restype = c.c_char_p
@@ -98,12 +114,11 @@ def lib():
     L.sfm_gpu_debug_mfma16_probe.argtypes = [vp, vp, vp, vp]
     L.sfm_gpu_debug_sqrt_probe.argtypes = [vp, vp]
     L.sfm_gpu_debug_ransac_dump.argtypes = [vp, c.c_int, vp, vp, vp, vp]
-    L.sfm_gpu_debug_set_score_filter.argtypes = [c.c_int]
+    L.sfm_gpu_debug_set_score_filter.argtypes = [vp, c.c_int]
     L.sfm_gpu_debug_pose_votes.argtypes = [vp, vp]
-    L.sfm_gpu_debug_set_score_prune.argtypes = [c.c_int]
+    L.sfm_gpu_debug_set_score_prune.argtypes = [vp, c.c_int]
     L.sfm_gpu_track_join.argtypes = [vp, vp, c.c_int, vp, c.c_int, vp, c.c_int, vp]
     L.sfm_gpu_recover_pose.argtypes = [vp, vp, vp, vp, c.c_int, vp, c.c_double, vp, vp, vp, vp]
-    _lib = L
     return L
 
 

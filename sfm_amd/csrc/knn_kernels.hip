@@ -361,7 +361,7 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
                         fc[nset][4 * (part - 4) + 3] = c[3];
                     }
                 }
-                if (u == 1 && ABLATE < 4) {
+                if (u == 1 && !(ABLATE & 4)) {
                     // stage s+1 has landed (this wave's share, then everyone's), and
                     // every wave is past its last read of stage s-1
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -372,15 +372,15 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
                 // piece at a time, instead of stalling this wave's MFMA stream in a burst
                 // (past the end the last stage is fetched again into the free buffer
                 // rather than branching around the issue)
-                if (u == 1 && ABLATE < 3) issue_stage(nx2, row_base + min(s + 2, n_stage - 1) * ST);
+                if (u == 1 && !(ABLATE & 2)) issue_stage(nx2, row_base + min(s + 2, n_stage - 1) * ST);
                 SFM_SB();
                 acc[u & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][1], bq[qb][1], acc[u & 1], 0, 0, 0);
                 SFM_SB();
-                if (ABLATE < 2) tmin = minima_lo(pa);
+                if (!(ABLATE & 1)) tmin = minima_lo(pa);
                 SFM_SB();
                 acc[u & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][2], bq[qb][2], acc[u & 1], 0, 0, 0);
                 SFM_SB();
-                if (ABLATE < 2) {
+                if (!(ABLATE & 1)) {
                     tmin = minima_hi(tmin, pa);
                     p = (tmin << TILE_BITS) | ptile;
                     if (u == 0) p |= first;
@@ -388,8 +388,8 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
                 SFM_SB();
                 acc[u & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[set][3], bq[qb][3], acc[u & 1], 0, 0, 0);
                 SFM_SB();
-                if (ABLATE < 2) {
-                    const uint32_t n3 = umin32(m3[pqb], umax32(m2[pqb], p));
+                if (!(ABLATE & 1)) {
+                    const uint32_t n3 = umed3(m2[pqb], m3[pqb], p);
                     const uint32_t n2 = umed3(m1[pqb], m2[pqb], p);
                     m1[pqb] = umin32(m1[pqb], p);
                     m2[pqb] = n2;
@@ -405,11 +405,11 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
         // nothing of this workgroup may still be in flight towards LDS when it ends
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // digest of the very last unit
-        if (ABLATE < 2) {
+        if (!(ABLATE & 1)) {
             const v16i& pa = acc[(U - 1) & 1];
             const uint32_t tmin = minima_hi(minima_lo(pa), pa);
             const uint32_t p = (tmin << TILE_BITS) | (uint32_t)(n_stage * (ST / 32) - 1);
-            const uint32_t n3 = umin32(m3[QB - 1], umax32(m2[QB - 1], p));
+            const uint32_t n3 = umed3(m2[QB - 1], m3[QB - 1], p);
             const uint32_t n2 = umed3(m1[QB - 1], m2[QB - 1], p);
             m1[QB - 1] = umin32(m1[QB - 1], p);
             m2[QB - 1] = n2;
@@ -470,7 +470,7 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
 typedef int v4acc __attribute__((ext_vector_type(4)));
 
 template <int WAVES, int ABLATE>
-__global__ void __launch_bounds__(WAVES * 64, 8 / WAVES)
+__global__ void __launch_bounds__(WAVES * 64, 2)  // two waves per SIMD, as one or two workgroups per CU
 knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblocks, int splits, int map_mode)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * LDS_STAGE];
@@ -486,7 +486,9 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
     const int c0 = wg.split * chunks_per_split;
     const int c1 = min(c0 + chunks_per_split, job.t_chunks);
 
-    const int wave = threadIdx.x >> 6;
+    // the wave number as a scalar: everything derived from it (LDS bases, DMA
+    // offsets, the cin branch) then stays in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int c16 = lane & 15;  // query within a block of 16 / train row within a tile
     const int kq = lane >> 4;   // which 16 bytes of each 64-byte half row / which row quartet
@@ -511,15 +513,31 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
     const uint32_t dma_off =
         (uint32_t)((8 * wave + dma_r) * DIM + ((dma_cs ^ (4 * (wave & 1) | (dma_r >> 1))) << 4));
     const uint32_t cin_off = (uint32_t)(lane & (ST / 4 - 1)) * 16u;
+    // LDS-DMA through buffer descriptors: the row base travels in a scalar
+    // offset, the lane part in one constant VGPR, so an issue costs no vector
+    // arithmetic (buffer_load_dwordx4 ... offen lds)
+    const __amdgpu_buffer_rsrc_t rs_desc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)job.t_desc, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cin =
+        __builtin_amdgcn_make_buffer_rsrc((void*)job.t_cin, 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned long long cin_exec = wave == WAVES - 1 ? (1ull << (ST / 4)) - 1ull : 0ull;
     auto issue_stage = [&](int bufi, int row0) {
         unsigned char* dst = lds + bufi * LDS_STAGE;
 #pragma unroll
-        for (int j = 0; j < PIECES; ++j) {
-            const int8_t* base = job.t_desc + (size_t)row0 * DIM + (size_t)j * (WAVES * 1024);
-            glds16(base + dma_off, dst + (wave + j * WAVES) * 1024);
-        }
-        const unsigned char* cbase = (const unsigned char*)(job.t_cin + row0);
-        if (wave == WAVES - 1 && lane < ST / 4) glds16(cbase + cin_off, dst + LDS_DESC);
+        for (int j = 0; j < PIECES; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rs_desc, (__attribute__((address_space(3))) void*)(dst + (wave + j * WAVES) * 1024), 16,
+                (int)dma_off, row0 * DIM + j * (WAVES * 1024), 0, 0);
+        // cin[ST]: 32 lanes of the last wave.  Predicated through EXEC without a
+        // branch (a branch here would split the pinned instruction stream into
+        // basic blocks and let the compiler move the digest across the MFMAs);
+        // every lane is active at this point of the kernel.
+        const unsigned cin_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(dst + LDS_DESC);
+        asm volatile(
+            "s_mov_b32 m0, %0\n\ts_mov_b64 exec, %1\n\ts_nop 0\n\t"
+            "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b64 exec, -1"
+            ::"s"(cin_lds), "s"(cin_exec), "v"(cin_off), "s"(rs_cin), "s"(row0 * 4)
+            : "memory");
     };
 
     // fragment addresses: row 16*tile + c16 has swizzle term (c16 >> 1) & 7 for
@@ -603,62 +621,62 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
                 } else {
                     read_part(nset, nb, nblk, 4 + qb);
                 }
-                if (u == 1 && ABLATE < 4) {
+                if (u == 1 && !(ABLATE & 4)) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     SFM_SB();
                 }
-                if (u == 1 && ABLATE < 3) issue_stage(nx2, row_base + min(s + 2, n_stage - 1) * ST);
+                if (u == 1 && !(ABLATE & 2)) issue_stage(nx2, row_base + min(s + 2, n_stage - 1) * ST);
                 SFM_SB();
                 ca[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][1][0], bq[qb][0], fc[set][1], 0, 0, 0);
                 SFM_SB();
                 // the digest of the previous unit, two instructions per MFMA gap
-                if (ABLATE < 2) {
+                if (!(ABLATE & 1)) {
                     tmin = umin32((uint32_t)pa[0][0], (uint32_t)pa[0][1]);
                     tmin = umin32(umin32(tmin, (uint32_t)pa[0][2]), (uint32_t)pa[0][3]);
                 }
                 SFM_SB();
                 ca[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][2][0], bq[qb][0], fc[set][2], 0, 0, 0);
                 SFM_SB();
-                if (ABLATE < 2) {
+                if (!(ABLATE & 1)) {
                     tmin = umin32(umin32(tmin, (uint32_t)pa[1][0]), (uint32_t)pa[1][1]);
                     tmin = umin32(umin32(tmin, (uint32_t)pa[1][2]), (uint32_t)pa[1][3]);
                 }
                 SFM_SB();
                 ca[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][3][0], bq[qb][0], fc[set][3], 0, 0, 0);
                 SFM_SB();
-                if (ABLATE < 2) {
+                if (!(ABLATE & 1)) {
                     tmin = umin32(umin32(tmin, (uint32_t)pa[2][0]), (uint32_t)pa[2][1]);
                     tmin = umin32(umin32(tmin, (uint32_t)pa[2][2]), (uint32_t)pa[2][3]);
                 }
                 SFM_SB();
                 ca[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][0][1], bq[qb][1], ca[0], 0, 0, 0);
                 SFM_SB();
-                if (ABLATE < 2) {
+                if (!(ABLATE & 1)) {
                     tmin = umin32(umin32(tmin, (uint32_t)pa[3][0]), (uint32_t)pa[3][1]);
                     tmin = umin32(umin32(tmin, (uint32_t)pa[3][2]), (uint32_t)pa[3][3]);
                 }
                 SFM_SB();
                 ca[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][1][1], bq[qb][1], ca[1], 0, 0, 0);
                 SFM_SB();
-                uint32_t mx = 0;
-                if (ABLATE < 2) {
+                if (!(ABLATE & 1)) {
                     p = (tmin << TILE_BITS) | ptile;
                     if (u == 0) p |= first;
-                    mx = umax32(m2[pqb], p);
                 }
                 SFM_SB();
                 ca[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][2][1], bq[qb][1], ca[2], 0, 0, 0);
                 SFM_SB();
+                // m1 <= m2 <= m3 are the three smallest so far: the new third is the
+                // middle of (m2, m3, p), the new second the middle of (m1, m2, p)
                 uint32_t n2 = 0;
-                if (ABLATE < 2) {
-                    m3[pqb] = umin32(m3[pqb], mx);
+                if (!(ABLATE & 1)) {
+                    m3[pqb] = umed3(m2[pqb], m3[pqb], p);
                     n2 = umed3(m1[pqb], m2[pqb], p);
                 }
                 SFM_SB();
                 ca[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][3][1], bq[qb][1], ca[3], 0, 0, 0);
                 SFM_SB();
-                if (ABLATE < 2) {
+                if (!(ABLATE & 1)) {
                     m1[pqb] = umin32(m1[pqb], p);
                     m2[pqb] = n2;
                 } else {
@@ -670,11 +688,11 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
             cur = nxt;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (ABLATE < 2) {
+        if (!(ABLATE & 1)) {
             const v4acc* pa = acc[(U - 1) & 1];
             const uint32_t tmin = digest_b(digest_a(pa), pa);
             const uint32_t p = (tmin << TILE_BITS) | (uint32_t)(n_stage * NBLK - 1);
-            const uint32_t n3 = umin32(m3[QB - 1], umax32(m2[QB - 1], p));
+            const uint32_t n3 = umed3(m2[QB - 1], m3[QB - 1], p);
             const uint32_t n2 = umed3(m1[QB - 1], m2[QB - 1], p);
             m1[QB - 1] = umin32(m1[QB - 1], p);
             m2[QB - 1] = n2;
@@ -1205,15 +1223,17 @@ hipError_t launch_prep_rows(hipStream_t s, const PrepJob* jobs_dev, int n_jobs, 
 //   0: 4 x 4 (512 queries / workgroup)   1: 2 x 4 (256)
 //   2: 2 x 8 (512)                       3: 4 x 8 (1024)
 //   4: 16x16x64 MFMAs, 8 x 4 waves (512 queries / workgroup), groups over 64-row blocks
-static const int kVariantQPB[5] = {512, 256, 512, 1024, 512};
+//   5: the same with 8 waves (1024 queries / workgroup, one workgroup per CU): half the
+//      LDS-DMA instructions per MFMA
+static const int kVariantQPB[6] = {512, 256, 512, 1024, 512, 1024};
 
 KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant)
 {
     KnnPlan p;
     p.ablate = force_variant >= 0 ? force_variant / 16 : 0;
     if (force_variant >= 0) force_variant %= 16;
-    p.variant = (force_variant >= 0 && force_variant < 5) ? force_variant : 4;  // 16x16x64 unless forced
-    p.group_mode = p.variant == 4 ? 1 : 0;
+    p.variant = (force_variant >= 0 && force_variant < 6) ? force_variant : 4;  // 16x16x64 unless forced
+    p.group_mode = p.variant >= 4 ? 1 : 0;
     p.q_per_block = kVariantQPB[p.variant];
     const int t_chunks = (n_train_max + CHUNK - 1) / CHUNK;
     const long long qblocks = (long long)((n_query_max + p.q_per_block - 1) / p.q_per_block) * n_jobs;
@@ -1258,26 +1278,54 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
 #define SFM_KNN2(QB, WAVES, ABL)                                                                  \
     hipLaunchKernelGGL((knn2_mfma_kernel<QB, WAVES, ABL>), grid, dim3(WAVES * 64), 0, s, jobs_dev, \
                        plan.chunks_per_split, qblocks, splits, mode)
+#define SFM_KNN16W(W, ABL)                                                                       \
+    hipLaunchKernelGGL((knn2_mfma16_kernel<W, ABL>), grid, dim3(W * 64), 0, s, jobs_dev, plan.chunks_per_split, \
+                       qblocks, splits, mode)
+#define SFM_KNN16(ABL)              \
+    do {                            \
+        if (plan.variant == 5)      \
+            SFM_KNN16W(8, ABL);     \
+        else                        \
+            SFM_KNN16W(4, ABL);     \
+    } while (0)
+    if (plan.ablate != 0) {
+#ifdef SFM_GPU_TIMING_BUILD
+        // timing experiments (wrong results): parts of the kernel switched off
+        if (plan.variant == 4 || plan.variant == 5) {
+            switch (plan.ablate) {
+                case 1: SFM_KNN16(1); break;
+                case 2: SFM_KNN16(2); break;
+                case 3: SFM_KNN16(3); break;
+                case 4: SFM_KNN16(4); break;
+                case 6: SFM_KNN16(6); break;
+                case 7: SFM_KNN16(7); break;
+                default: return hipErrorInvalidValue;
+            }
+        } else if (plan.variant == 0) {
+            switch (plan.ablate) {
+                case 1: SFM_KNN2(4, 4, 1); break;
+                case 3: SFM_KNN2(4, 4, 3); break;
+                case 7: SFM_KNN2(4, 4, 7); break;
+                default: return hipErrorInvalidValue;
+            }
+        } else {
+            return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+#else
+        return hipErrorInvalidValue;
+#endif
+    }
     switch (plan.variant) {
         case 1: SFM_KNN2(2, 4, 0); break;
         case 2: SFM_KNN2(2, 8, 0); break;
         case 3: SFM_KNN2(4, 8, 0); break;
         case 4:
-#define SFM_KNN16(ABL)                                                                            \
-    hipLaunchKernelGGL((knn2_mfma16_kernel<4, ABL>), grid, dim3(256), 0, s, jobs_dev, plan.chunks_per_split, \
-                       qblocks, splits, mode)
-            if (plan.ablate == 2) SFM_KNN16(2);
-            else if (plan.ablate == 4) SFM_KNN16(4);
-            else SFM_KNN16(0);
-#undef SFM_KNN16
-            break;
-        default:
-            if (plan.ablate == 2) SFM_KNN2(4, 4, 2);
-            else if (plan.ablate == 3) SFM_KNN2(4, 4, 3);
-            else if (plan.ablate == 4) SFM_KNN2(4, 4, 4);
-            else SFM_KNN2(4, 4, 0);
-            break;
+        case 5: SFM_KNN16(0); break;
+        default: SFM_KNN2(4, 4, 0); break;
     }
+#undef SFM_KNN16
+#undef SFM_KNN16W
 #undef SFM_KNN2
     return hipGetLastError();
 }

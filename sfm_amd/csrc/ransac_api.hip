@@ -176,7 +176,8 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             const int s1_pts = (stage1 + 127) / 128 * 128;
             if (ctx->hint_points - s1_pts >= 1024.0) mid = s1_pts + (int)(0.35 * (ctx->hint_points - s1_pts));
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh, stage1, mid));
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh, stage1, mid, ctx->score_filter,
+                                             ctx->score_prune));
         }
         {
             // winner, then its mask and model copy, by the same workgroup per problem
@@ -222,7 +223,8 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         }
         {
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, done_rows, b, 0, 0));
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, done_rows, b, 0, 0, ctx->score_filter,
+                                             ctx->score_prune));
         }
         counts.resize((size_t)n_prob * b * 10);
         // the problems' workspaces are carved at a constant stride: one strided copy
@@ -316,15 +318,24 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
 
 extern "C" {
 
-int sfm_gpu_debug_set_score_filter(int on)
+int sfm_gpu_debug_set_score_filter(sfm_gpu_ctx* ctx, int on)
 {
-    sfm::set_ransac_score_filter(on);
+    if (!ctx) return SFM_GPU_ERR_ARG;
+#ifdef SFM_GPU_TIMING_BUILD
+    const int max_mode = 3;  // 2, 3: timing experiments with wrong counts
+#else
+    const int max_mode = 1;
+#endif
+    if (on < 0 || on > max_mode) return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "score filter mode %d", on);
+    ctx->score_filter = on;
     return SFM_GPU_OK;
 }
 
-int sfm_gpu_debug_set_score_prune(int on)
+int sfm_gpu_debug_set_score_prune(sfm_gpu_ctx* ctx, int on)
 {
-    sfm::set_ransac_score_prune(on);
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    if (on < 0 || on > 2) return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "score prune mode %d", on);
+    ctx->score_prune = on;
     return SFM_GPU_OK;
 }
 

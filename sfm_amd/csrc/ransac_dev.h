@@ -114,10 +114,11 @@ hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_pro
 // models that provably cannot reach the best count are dropped (their counts
 // stay partial) and the rest go on; the selected model, its count and the mask
 // are the same as with prune = 0.
+// filter_mode: 1 = float32 filter with a rigorous bound in front of the double
+// precision test, 0 = double precision only (same counts).  prune_mode: 0 = never
+// drop a model, 1 = as described above, 2 = at most one cut.
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
-                               int n_hyp, int prune, int mid);
-void set_ransac_score_filter(int on);
-void set_ransac_score_prune(int on);
+                               int n_hyp, int prune, int mid, int filter_mode, int prune_mode);
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
 
 // One image pair between the k-NN output and RANSAC (pair_kernels.hip).

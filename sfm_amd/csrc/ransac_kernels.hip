@@ -1637,7 +1637,9 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
     int n_parked = 0;
     if (use_filter) {
         auto park = [&](int idx) {
+#ifdef SFM_GPU_TIMING_BUILD
             if (use_filter >= 2) return;  // timing experiments: unsettled tests are dropped (wrong counts)
+#endif
             if (n_parked < QCAP) {
                 parked[n_parked * 64 + lane] = (unsigned short)(idx - i0);
                 ++n_parked;
@@ -1934,13 +1936,6 @@ __global__ void __launch_bounds__(256) ransac_mask_kernel(const RansacProb* __re
 
 }  // namespace
 
-// test hook: 0 scores every point in double precision only
-int g_score_filter = 1;
-void set_ransac_score_filter(int on) { g_score_filter = on; }
-// test hook: 0 scores every listed model on every point even where pruning is allowed
-int g_score_prune = 1;
-void set_ransac_score_prune(int on) { g_score_prune = on; }
-
 hipError_t launch_ransac_prep(hipStream_t s, const RansacProb* probs, int n_prob, int cap)
 {
     hipLaunchKernelGGL(ransac_prep_kernel, dim3((cap + 255) / 256 > 0 ? (cap + 255) / 256 : 1, n_prob),
@@ -1975,7 +1970,7 @@ hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_pro
     return hipGetLastError();
 }
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
-                               int n_hyp, int prune, int mid)
+                               int n_hyp, int prune, int mid, int filter_mode, int prune_mode)
 {
     const int maxm = model == SFM_GPU_MODEL_ESSENTIAL ? 10 : 3;
     hipLaunchKernelGGL(ransac_compact_kernel, dim3(n_prob), dim3(1024), 0, s, probs, hyp0, n_hyp, maxm);
@@ -1985,7 +1980,7 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     // strided: the grid is smaller than the work and its workgroups loop
     auto score = [&](int chunk_pts, int chunk0, int chunks, unsigned gx, int pts_end, bool strided) {
         const dim3 grid((gx + SCORE_WAVES - 1) / SCORE_WAVES, chunks, n_prob), block(SCORE_WAVES * 64);
-        const int f = g_score_filter;
+        const int f = filter_mode;
         if (model == SFM_GPU_MODEL_ESSENTIAL) {
             if (strided)
                 hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL, true>), grid, block, 0, s, probs,
@@ -2015,7 +2010,7 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     // split into equal pieces of at most 256
     const int p1 = (prune + 127) / 128 * 128;
     const int p_end = n_chunks * chunk;
-    if (prune > 0 && g_score_prune && p_end > p1) {
+    if (prune > 0 && prune_mode && p_end > p1) {
         const int ny = (p1 + 255) / 256;
         score(((p1 + ny - 1) / ny + 3) & ~3, 0, ny, groups, p1, false);
         hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, p1);
@@ -2024,7 +2019,7 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
         // deep that strides over whatever is left (measured best among widths
         // 1/2..1/32, depths 8..64 and pieces of 32..128 points)
         int pm = (mid + 127) / 128 * 128;
-        if (!(g_score_prune == 1 && pm > p1 && pm < p_end)) pm = 0;
+        if (!(prune_mode == 1 && pm > p1 && pm < p_end)) pm = 0;
         if (pm) {
             const int c = (pm - p1) / 128;
             score(128, p1 / 128, c < 32 ? c : 32, (groups + 7) / 8, pm, true);

@@ -123,6 +123,8 @@ struct sfm_gpu_ctx {
     bool own_stream = false;
     std::string err;
     int knn_variant = -1;  // -1: planner decides
+    int score_filter = 1;  // test hooks of the RANSAC scoring pass (sfm_gpu_debug.h)
+    int score_prune = 1;
     // this device's copy of the library's static working memory (the calls that
     // must not allocate work there); resolved once per device at creation
     void* static_scratch = nullptr;

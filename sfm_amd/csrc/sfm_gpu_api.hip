@@ -223,7 +223,14 @@ hipError_t resolve_scratch(int device, void** out)
 
 extern "C" {
 
-const char* sfm_gpu_version(void) { return "sfm_gpu 0.1 gfx950"; }
+const char* sfm_gpu_version(void)
+{
+#ifdef SFM_GPU_TIMING_BUILD
+    return "sfm_gpu 0.2 gfx950 timing-build";
+#else
+    return "sfm_gpu 0.2 gfx950";
+#endif
+}
 
 int sfm_gpu_create(int device_id, void* hip_stream, sfm_gpu_ctx** out)
 {
@@ -585,7 +592,11 @@ int sfm_gpu_profile_query(sfm_gpu_ctx* c, const char* kernel, double* total_ms, 
 int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* c, int variant)
 {
     if (!c) return SFM_GPU_ERR_ARG;
-    c->knn_variant = variant;
+#ifndef SFM_GPU_TIMING_BUILD
+    if (variant >= 16) return c->fail(SFM_GPU_ERR_UNSUPPORTED, "timing ablations exist in the timing build only");
+#endif
+    if (variant >= 0 && variant % 16 > 5) return c->fail(SFM_GPU_ERR_UNSUPPORTED, "unknown sweep shape %d", variant % 16);
+    c->knn_variant = variant < 0 ? -1 : variant;
     return SFM_GPU_OK;
 }
 

@@ -93,7 +93,9 @@ struct KnnPlan {
     int chunks_per_split;
     int q_per_block;
     int variant;
-    int ablate;  // timing experiments only: 2 = MFMA only, 3 = no DMA, 4 = no barrier either (wrong results)
+    // timing experiments only, honoured by the timing build alone (wrong results): bit 0 = no
+    // digest of the accumulators, bit 1 = no DMA of further stages, bit 2 = no stage barrier
+    int ablate;
     int group_mode;  // geometry of the row groups in the sweep's records: 0 = 32x32 tiles, 1 = 16x16 tiles
 };
 KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant);

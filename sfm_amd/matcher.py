@@ -24,8 +24,10 @@ FM_RANSAC = 8  # cv::FM_RANSAC == cv::RANSAC
 class Context:
     """One GPU + one HIP stream (sfm_gpu_create)."""
 
-    def __init__(self, device_id=0, stream=None):
-        self._L = _lib.lib()
+    def __init__(self, device_id=0, stream=None, timing_build=False):
+        # timing_build: the library variant that carries the kernels' timing
+        # ablations (measurement scripts only)
+        self._L = _lib.timing_lib() if timing_build else _lib.lib()
         h = ctypes.c_void_p()
         rc = self._L.sfm_gpu_create(device_id, ctypes.c_void_p(stream) if stream else None,
                                     ctypes.byref(h))

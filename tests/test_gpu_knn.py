@@ -51,7 +51,7 @@ def test_mfma16_operand_and_accumulator_layout(gpu_ctx):
     assert (c == a.astype(np.int32) @ b.astype(np.int32).T).all()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("nq,nt", [(1, 1), (5, 2), (33, 257), (257, 1000), (700, 3000)])
 def test_knn_small_shapes(gpu_ctx, oracle, variant, nq, nt):
     gpu_ctx._L.sfm_gpu_debug_set_knn_variant(gpu_ctx.handle, variant)
@@ -63,7 +63,7 @@ def test_knn_small_shapes(gpu_ctx, oracle, variant, nq, nt):
     gpu_ctx._L.sfm_gpu_debug_set_knn_variant(gpu_ctx.handle, -1)
 
 
-@pytest.fixture(params=[-1, 0], ids=["planner_mfma16x16", "mfma32x32"])
+@pytest.fixture(params=[-1, 0, 5], ids=["planner_mfma16x16", "mfma32x32", "mfma16x16_8waves"])
 def sweep_shape(request, gpu_ctx):
     """Runs a test with the planner's choice and with each MFMA shape of the sweep forced."""
     gpu_ctx._L.sfm_gpu_debug_set_knn_variant(gpu_ctx.handle, request.param)

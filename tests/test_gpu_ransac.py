@@ -29,9 +29,9 @@ def _dump(ctx, n_hyp, m):
 def full_counts(gpu_ctx):
     """Fixed-count scoring normally drops models that cannot win between its
     stages; tests that compare every hypothesis' count switch that off."""
-    gpu_ctx._L.sfm_gpu_debug_set_score_prune(0)
+    gpu_ctx._L.sfm_gpu_debug_set_score_prune(gpu_ctx.handle, 0)
     yield
-    gpu_ctx._L.sfm_gpu_debug_set_score_prune(1)
+    gpu_ctx._L.sfm_gpu_debug_set_score_prune(gpu_ctx.handle, 1)
 
 
 def _model_close(a, b, tol=1e-6):
@@ -191,7 +191,7 @@ def test_scoring_filter_is_exact_on_near_threshold_points(gpu_ctx, oracle, full_
                       sample_table=table, want_counts=True)
     res = {}
     for filt in (1, 0):
-        gpu_ctx._L.sfm_gpu_debug_set_score_filter(filt)
+        gpu_ctx._L.sfm_gpu_debug_set_score_filter(gpu_ctx.handle, filt)
         try:
             if model == 0:
                 _, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, K, prob=0.99, threshold=thr,
@@ -201,7 +201,7 @@ def test_scoring_filter_is_exact_on_near_threshold_points(gpu_ctx, oracle, full_
                                                         confidence=0.99, mode=matcher.RANSAC_FIXED,
                                                         sample_table=table)
         finally:
-            gpu_ctx._L.sfm_gpu_debug_set_score_filter(1)
+            gpu_ctx._L.sfm_gpu_debug_set_score_filter(gpu_ctx.handle, 1)
         _, _, counts, _ = _dump(gpu_ctx, len(table), 5 if model == 0 else 7)
         res[filt] = (counts.copy(), mask.copy(), r["n_inliers"])
         assert (counts == o["counts"]).all()
