@@ -250,15 +250,15 @@ int sfm_gpu_knn_match_images(sfm_gpu_ctx* ctx, const sfm_gpu_image* query,
  * harnesses that forbid hipMalloc.  No counterpart in the reference.  The call
  * allocates nothing and copies nothing: the sweep records, the list of queries
  * for the float-ranked pass and the job descriptor live in a static device
- * array that is part of the library's code object (8.2 MiB per GPU, held until
+ * array that is part of the library's code object (16.2 MiB per GPU, held until
  * the process ends), and the call only enqueues kernels on the context's
  * stream.
  *
  *   matches_dev, counts_dev   device pointers, n_query*k records / n_query
  *                             counts, as sfm_gpu_knn_match_images writes them
- * Limits: at most 32768 query rows and 524288 sweep records (train parts x
- * query rows padded to 1024) -- every size up to 32768 x 262143 fits;
- * SFM_GPU_ERR_CAPACITY beyond.  All calls on one GPU share that GPU's array:
+ * Limits: at most 32768 query rows, and train parts x query rows (padded to
+ * 1024) at most 262144 -- 32768 x 32768 fits (8 parts), as does any smaller
+ * pair; SFM_GPU_ERR_CAPACITY beyond.  All calls on one GPU share that GPU's array:
  * two such calls that overlap in time on one GPU (different streams or
  * contexts) race; calls on one stream are ordered and safe.
  */

@@ -22,6 +22,22 @@ extern "C" {
  * SFM_GPU_ERR_UNSUPPORTED. */
 int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* ctx, int variant);
 
+/* Enqueues a kernel that overwrites the LDS of every CU with a pattern.  A kernel
+ * that misses a DMA, or reads a stage before it has landed, otherwise reads what
+ * the previous kernel left in LDS, which in a test is often the right data. */
+int sfm_gpu_debug_poison_lds(sfm_gpu_ctx* ctx, uint32_t pattern);
+
+/* The first `bytes` of the sweep records the last k-NN call on this context left
+ * ([train part][padded query row][4] x {best group, second group, third group,
+ * first unit of the part}; a group is (x << 9 | unit within the part)). */
+int sfm_gpu_debug_copy_records(sfm_gpu_ctx* ctx, void* out, size_t bytes);
+
+/* Timing build only (SFM_GPU_ERR_UNSUPPORTED otherwise): per workgroup of the last
+ * 16x16 sweep launch, 8 words: wall clock at entry (100 MHz ticks), shader cycle
+ * counter at entry, after the prologue, after the last stage, at exit, wall clock
+ * at exit, XCC id, unused.  In the default build the kernel carries no stamp. */
+int sfm_gpu_debug_sweep_stamps(sfm_gpu_ctx* ctx, uint64_t* out, int n_wg);
+
 /* Number of queries that the last k-NN call on this context (its first job)
  * sent through the exhaustive float-ranked pass. */
 int sfm_gpu_debug_redo_count(sfm_gpu_ctx* ctx, int32_t* out);

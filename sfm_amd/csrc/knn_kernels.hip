@@ -19,6 +19,7 @@
 // queries where that shortcut is not provably exact go through an exhaustive
 // float-ranked pass.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "sfm_internal.h"
@@ -185,6 +186,27 @@ __device__ __forceinline__ WgCoord decode_wg(uint32_t id, uint32_t qblocks, uint
 }
 
 #define SFM_SB() __builtin_amdgcn_sched_barrier(0)
+
+// In-kernel stamps of the 16x16 sweep, timing build only (in the product build
+// no stamp executes): per workgroup {realtime at entry, cycle counter at entry,
+// after the prologue, after the last stage, at exit, realtime at exit, XCC id}.
+#ifdef SFM_GPU_TIMING_BUILD
+constexpr int SWEEP_STAMP_WGS = 8192;
+__device__ unsigned long long g_sweep_stamps[SWEEP_STAMP_WGS * 8];
+#define SFM_STAMP(slot)                                                                         \
+    do {                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < SWEEP_STAMP_WGS)                                   \
+            g_sweep_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();             \
+    } while (0)
+#define SFM_STAMP_REAL(slot)                                                                    \
+    do {                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < SWEEP_STAMP_WGS)                                   \
+            g_sweep_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();         \
+    } while (0)
+#else
+#define SFM_STAMP(slot) do { } while (0)
+#define SFM_STAMP_REAL(slot) do { } while (0)
+#endif
 
 // Distance sweep.  Workgroup = WAVES waves, each owning QB blocks of 32
 // queries whose fragments stay in registers; the workgroup streams one part of
@@ -419,40 +441,15 @@ knn2_mfma_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qblo
         }
     }
 
-    // Lanes l and l+32 hold the same query over disjoint groups: merge their
-    // triples; lane l < 32 writes one record per (split, query):
+    // Lanes l and l+32 hold the same query over disjoint groups; each writes its
+    // own record (sub = half h), the neighbour extraction merges them:
     //   x = best group (x << 9 | tile), y = second group, z = third minimum,
-    //   w = first tile of the sweep | half of best << 28 | half of second << 30
+    //   w = first tile of the sweep
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        typedef unsigned long long u64;
-        const u64 NONE = ~0ull;
-        auto key = [&](uint32_t p, int hh) -> u64 {
-            return p == 0xFFFFFFFFu ? NONE : (((u64)p << 1) | (u64)hh);
-        };
-        const uint32_t o1 = (uint32_t)__shfl_xor((int)m1[qb], 32);
-        const uint32_t o2 = (uint32_t)__shfl_xor((int)m2[qb], 32);
-        const uint32_t o3 = (uint32_t)__shfl_xor((int)m3[qb], 32);
-        u64 k1 = key(m1[qb], h), k2 = key(m2[qb], h), k3 = key(m3[qb], h);
-        const u64 b[3] = {key(o1, h ^ 1), key(o2, h ^ 1), key(o3, h ^ 1)};
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const u64 v = b[j];
-            if (v < k3) {
-                k3 = v;
-                if (k3 < k2) { const u64 t = k2; k2 = k3; k3 = t; }
-                if (k2 < k1) { const u64 t = k1; k1 = k2; k2 = t; }
-            }
-        }
-        if (h == 0) {
-            const int q = q_base + qb * 32 + col;
-            uint4 o;
-            o.x = k1 == NONE ? 0xFFFFFFFFu : (uint32_t)(k1 >> 1);
-            o.y = k2 == NONE ? 0xFFFFFFFFu : (uint32_t)(k2 >> 1);
-            o.z = k3 == NONE ? 0xFFFFFFFFu : (uint32_t)(k3 >> 1);
-            o.w = (uint32_t)(c0 * (CHUNK / 32)) | ((uint32_t)(k1 & 1) << 28) | ((uint32_t)(k2 & 1) << 30);
-            job.partial[(size_t)wg.split * job.q_rows_alloc + q] = o;
-        }
+        const int q = q_base + qb * 32 + col;
+        const uint4 o = make_uint4(m1[qb], m2[qb], m3[qb], (uint32_t)(c0 * (CHUNK / 32)));
+        job.partial[((size_t)wg.split * job.q_rows_alloc + q) * REC_SUBS + h] = o;
     }
 }
 
@@ -481,6 +478,8 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
     constexpr int QPB = WAVES * QB * 16;
 
     const WgCoord wg = decode_wg(blockIdx.x, (uint32_t)qblocks, (uint32_t)splits, map_mode);
+    SFM_STAMP_REAL(0);
+    SFM_STAMP(1);
     const KnnJob job = jobs[wg.job];
     if (wg.qblock * QPB >= job.n_query) return;
     const int c0 = wg.split * chunks_per_split;
@@ -521,23 +520,31 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
     const __amdgpu_buffer_rsrc_t rs_cin =
         __builtin_amdgcn_make_buffer_rsrc((void*)job.t_cin, 0, 0x7FFFFFFF, 0x00020000);
     const unsigned long long cin_exec = wave == WAVES - 1 ? (1ull << (ST / 4)) - 1ull : 0ull;
-    auto issue_stage = [&](int bufi, int row0) {
+    auto issue_piece = [&](int bufi, int row0, int j) {
         unsigned char* dst = lds + bufi * LDS_STAGE;
-#pragma unroll
-        for (int j = 0; j < PIECES; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rs_desc, (__attribute__((address_space(3))) void*)(dst + (wave + j * WAVES) * 1024), 16,
-                (int)dma_off, row0 * DIM + j * (WAVES * 1024), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rs_desc, (__attribute__((address_space(3))) void*)(dst + (wave + j * WAVES) * 1024), 16,
+            (int)dma_off, row0 * DIM + j * (WAVES * 1024), 0, 0);
+    };
+    auto issue_cin = [&](int bufi, int row0) {
+        unsigned char* dst = lds + bufi * LDS_STAGE;
         // cin[ST]: 32 lanes of the last wave.  Predicated through EXEC without a
         // branch (a branch here would split the pinned instruction stream into
         // basic blocks and let the compiler move the digest across the MFMAs);
         // every lane is active at this point of the kernel.
         const unsigned cin_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(dst + LDS_DESC);
+        unsigned saved_m0;  // M0 is restored: the compiler keeps track of what it put there for its own DMAs
         asm volatile(
-            "s_mov_b32 m0, %0\n\ts_mov_b64 exec, %1\n\ts_nop 0\n\t"
-            "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b64 exec, -1"
-            ::"s"(cin_lds), "s"(cin_exec), "v"(cin_off), "s"(rs_cin), "s"(row0 * 4)
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %2\n\ts_nop 0\n\t"
+            "buffer_load_dwordx4 %3, %4, %5 offen lds\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
+            : "=&s"(saved_m0)
+            : "s"(cin_lds), "s"(cin_exec), "v"(cin_off), "s"(rs_cin), "s"(row0 * 4)
             : "memory");
+    };
+    auto issue_stage = [&](int bufi, int row0) {
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) issue_piece(bufi, row0, j);
+        issue_cin(bufi, row0);
     };
 
     // fragment addresses: row 16*tile + c16 has swizzle term (c16 >> 1) & 7 for
@@ -591,6 +598,7 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[1][j][i] = 0;
+        SFM_STAMP(2);
 
         int cur = 0;
         uint32_t first = 0xFFFFFFFFu;
@@ -626,7 +634,13 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
                     __builtin_amdgcn_s_barrier();
                     SFM_SB();
                 }
-                if (u == 1 && !(ABLATE & 2)) issue_stage(nx2, row_base + min(s + 2, n_stage - 1) * ST);
+                // the DMA of stage s+2, one piece per unit behind the barrier (a burst
+                // of them stalls the wave's MFMA stream for hundreds of cycles)
+                if (!(ABLATE & 2) && u >= 1 && u <= PIECES + 1) {
+                    const int row2 = row_base + min(s + 2, n_stage - 1) * ST;
+                    if (u <= PIECES) issue_piece(nx2, row2, u - 1);
+                    else issue_cin(nx2, row2);
+                }
                 SFM_SB();
                 ca[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[set][1][0], bq[qb][0], fc[set][1], 0, 0, 0);
                 SFM_SB();
@@ -687,6 +701,7 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
             first = 0;
             cur = nxt;
         }
+        SFM_STAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(ABLATE & 1)) {
             const v4acc* pa = acc[(U - 1) & 1];
@@ -703,41 +718,26 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
         }
     }
 
-    // The four lanes l&15 + 16*quarter hold the same query over disjoint groups:
-    // merge their triples (two butterfly steps); the quarter-0 lane writes one
-    // record per (part, query):
+    // The four lanes l&15 + 16*quarter hold the same query over disjoint groups;
+    // each writes its own record (sub = quarter), 1 KiB contiguous per wave and
+    // query block, and the neighbour extraction merges them:
     //   x = best group (x << 9 | block), y = second group, z = third minimum,
-    //   w = first block of the sweep | quarter of best << 28 | quarter of second << 30
+    //   w = first block of the sweep
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        typedef unsigned long long u64;
-        const u64 NONE = ~0ull;
-        auto key = [&](uint32_t p) -> u64 { return p == 0xFFFFFFFFu ? NONE : (((u64)p << 2) | (u64)kq); };
-        u64 k1 = key(m1[qb]), k2 = key(m2[qb]), k3 = key(m3[qb]);
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            const u64 b[3] = {(u64)__shfl_xor((unsigned long long)k1, off), (u64)__shfl_xor((unsigned long long)k2, off),
-                              (u64)__shfl_xor((unsigned long long)k3, off)};
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const u64 v = b[j];
-                if (v < k3) {
-                    k3 = v;
-                    if (k3 < k2) { const u64 t = k2; k2 = k3; k3 = t; }
-                    if (k2 < k1) { const u64 t = k1; k1 = k2; k2 = t; }
-                }
-            }
-        }
-        if (kq == 0) {
-            const int q = q_base + qb * 16 + c16;
-            uint4 o;
-            o.x = k1 == NONE ? 0xFFFFFFFFu : (uint32_t)(k1 >> 2);
-            o.y = k2 == NONE ? 0xFFFFFFFFu : (uint32_t)(k2 >> 2);
-            o.z = k3 == NONE ? 0xFFFFFFFFu : (uint32_t)(k3 >> 2);
-            o.w = (uint32_t)(c0 * (CHUNK / BLK)) | ((uint32_t)(k1 & 3) << 28) | ((uint32_t)(k2 & 3) << 30);
-            job.partial[(size_t)wg.split * job.q_rows_alloc + q] = o;
-        }
+        const int q = q_base + qb * 16 + c16;
+        const uint4 o = make_uint4(m1[qb], m2[qb], m3[qb], (uint32_t)(c0 * (CHUNK / BLK)));
+        job.partial[((size_t)wg.split * job.q_rows_alloc + q) * REC_SUBS + kq] = o;
     }
+    SFM_STAMP(4);
+    SFM_STAMP_REAL(5);
+#ifdef SFM_GPU_TIMING_BUILD
+    if (threadIdx.x == 0 && blockIdx.x < SWEEP_STAMP_WGS) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_sweep_stamps[blockIdx.x * 8 + 6] = xcc;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- rescan ----
@@ -778,7 +778,7 @@ __device__ __forceinline__ void insert3(u64& a1, u64& a2, u64& a3, u64 v)
 }
 
 // Exact neighbours from the sweep records.  32 lanes per query:
-//  1. the query's records (one per split) are reduced to the two best groups
+//  1. the query's records (one per part and sweep lane) are reduced to the two best groups
 //     by (minimum x, tile, half) and to the smallest x of all the other groups;
 //  2. the 32 rows of the two groups are laid over the 32 lanes in ascending row
 //     order and every lane computes the exact squared distance of its row;
@@ -799,6 +799,7 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
 {
     const double skip_r2 = ratio * ratio;  // 0 when the caller wants every neighbour
     constexpr int SB = GM ? 2 : 1;           // bits of the sub-unit index
+    constexpr int SUBS = 1 << SB;            // records per (part, query): one per lane holding the query
     constexpr int UROWS = GM ? 64 : 32;      // rows per unit
     constexpr int JSTRIDE = GM ? 16 : 8;     // row stride between the four runs of a group
     // same workgroup -> XCD affinity as the sweep: the gathers of one job's
@@ -823,15 +824,19 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
             auto key_of = [&](uint32_t p, uint32_t t0, uint32_t sub) -> u64 {
                 return ((u64)(p >> TILE_BITS) << 32) | (((t0 + (p & tmask)) << SB) | sub);
             };
-            for (int j = part; j < n_splits; j += 8) {
-                const uint4 r = job.partial[(size_t)j * job.q_rows_alloc + q];
-                const uint32_t t0 = r.w & 0x0FFFFFFFu;
-                if (r.x != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.x, t0, (r.w >> 28) & 3u));
-                if (r.y != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.y, t0, (r.w >> 30) & 3u));
-                if (r.z != 0xFFFFFFFFu) insert3(c1, c2, c3, ((u64)(r.z >> TILE_BITS) << 32) | 0xFFFFFFFFu);
+            // one record per (part, lane of the query in the sweep)
+            for (int j = part; j < n_splits * SUBS; j += 8) {
+                const int sp = j / SUBS;
+                const uint32_t sub = (uint32_t)(j - sp * SUBS);
+                const uint4 r = job.partial[((size_t)sp * job.q_rows_alloc + q) * REC_SUBS + sub];
+                const uint32_t t0 = r.w;
+                if (r.x != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.x, t0, sub));
+                if (r.y != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.y, t0, sub));
+                // a lane's third group may be the second best of all: it keeps its identity
+                if (r.z != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.z, t0, sub));
             }
         }
-        for (int off = 1; off < 8 && off < n_splits; off <<= 1) {
+        for (int off = 1; off < 8 && off < n_splits * SUBS; off <<= 1) {
             const u64 b1 = __shfl_xor(c1, off), b2 = __shfl_xor(c2, off), b3 = __shfl_xor(c3, off);
             insert3(c1, c2, c3, b1);
             insert3(c1, c2, c3, b2);
@@ -1190,6 +1195,17 @@ __global__ void __launch_bounds__(256) sqrt_probe_kernel(int32_t* mismatches)
     if (__float_as_uint(a) != __float_as_uint(b)) atomicAdd(mismatches, 1);
 }
 
+// Fills the whole LDS of the CU the workgroup lands on with a byte pattern.  A
+// kernel that skips a DMA or reads a stage before it landed would otherwise see
+// whatever the previous kernel left there -- often the right data of the same test.
+__global__ void __launch_bounds__(256) lds_poison_kernel(uint32_t pattern, uint32_t* sink)
+{
+    __shared__ uint32_t buf[163840 / 4];
+    for (int i = threadIdx.x; i < 163840 / 4; i += 256) buf[i] = pattern + (uint32_t)i * 2654435761u;
+    __syncthreads();
+    if (buf[(threadIdx.x * 97u + blockIdx.x) % (163840u / 4u)] == 0x12345678u && sink) sink[0] = 1;  // keeps the stores
+}
+
 // C(16x16) = A(16 rows x 64 k) * B^T (B given as [16 cols][64 k]) through one
 // v_mfma_i32_16x16x64_i8 with the operand and accumulator mapping the 16x16
 // sweep assumes.
@@ -1273,7 +1289,13 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
     const long long total = (long long)qblocks * splits * n_jobs;
     if (total <= 0) return hipSuccess;
     if (total > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    const int mode = (n_jobs % 8 == 0) ? 1 : (splits % 8 == 0) ? 2 : 0;
+    // a lone job runs fastest in plain order (its workgroups load their query blocks
+    // in one burst at the start: with the query block varying fastest each XCD
+    // fetches an eighth of them instead of all)
+    int mode = (n_jobs % 8 == 0) ? 1 : (n_jobs > 1 && splits % 8 == 0) ? 2 : 0;
+#ifdef SFM_GPU_TIMING_BUILD
+    if (const char* e = getenv("SFM_KNN_MAP_MODE")) mode = atoi(e);  // placement experiments
+#endif
     const dim3 grid((unsigned)total);
 #define SFM_KNN2(QB, WAVES, ABL)                                                                  \
     hipLaunchKernelGGL((knn2_mfma_kernel<QB, WAVES, ABL>), grid, dim3(WAVES * 64), 0, s, jobs_dev, \
@@ -1361,6 +1383,18 @@ hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, in
     return hipGetLastError();
 }
 
+hipError_t read_sweep_stamps(unsigned long long* out, int n_wg)
+{
+#ifdef SFM_GPU_TIMING_BUILD
+    if (n_wg > SWEEP_STAMP_WGS) n_wg = SWEEP_STAMP_WGS;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_stamps), (size_t)n_wg * 64);
+#else
+    (void)out;
+    (void)n_wg;
+    return hipErrorNotSupported;
+#endif
+}
+
 hipError_t launch_mfma_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c)
 {
     hipLaunchKernelGGL(mfma_layout_probe_kernel, dim3(1), dim3(64), 0, s, a, b, c);
@@ -1369,6 +1403,11 @@ hipError_t launch_mfma_layout_probe(hipStream_t s, const int8_t* a, const int8_t
 hipError_t launch_sqrt_probe(hipStream_t s, int32_t* mismatches)
 {
     hipLaunchKernelGGL(sqrt_probe_kernel, dim3((1u << 24) / 256), dim3(256), 0, s, mismatches);
+    return hipGetLastError();
+}
+hipError_t launch_lds_poison(hipStream_t s, uint32_t pattern)
+{
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 0, s, pattern, (uint32_t*)nullptr);
     return hipGetLastError();
 }
 hipError_t launch_mfma16_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c)

@@ -522,7 +522,7 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
     const KnnPlan plan = plan_knn(pl.nq_max, pl.nt_max, g, ctx->knn_variant);
     // a smaller (last) group may be planned with more train parts per job: size
     // the record buffer from this group's own plan
-    const size_t partial_b = align_up((size_t)plan.n_splits * pl.qalloc_max * sizeof(uint4), 256);
+    const size_t partial_b = align_up((size_t)plan.n_splits * pl.qalloc_max * REC_SUBS * sizeof(uint4), 256);
     SFM_HIP(ctx, ctx->partial.reserve(partial_b * g));
     for (int i = 0; i < g; ++i) {
         const ImageDev& q = images[pairs[2 * (g0 + i)]]->d;

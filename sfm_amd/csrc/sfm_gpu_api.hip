@@ -113,7 +113,7 @@ __global__ void store_knn_job_kernel(KnnJob job, KnnJob* dst, int32_t* redo_coun
 
 // Device memory a k-NN call works in besides its inputs and outputs.
 struct KnnWorkspace {
-    uint4* partial;   // [n_splits][q.rows_alloc] sweep records
+    uint4* partial;   // [n_splits][q.rows_alloc][REC_SUBS] sweep records
     int32_t* redo;    // [1 + n_query]
     KnnJob* job;
 };
@@ -163,7 +163,7 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
     const int nq = q.n, nt = t.n;
     if (nq == 0) return SFM_GPU_OK;
     const KnnPlan plan = plan_knn(nq, nt, 1, ctx->knn_variant);
-    SFM_HIP(ctx, ctx->partial.reserve((size_t)plan.n_splits * q.rows_alloc * sizeof(uint4)));
+    SFM_HIP(ctx, ctx->partial.reserve((size_t)plan.n_splits * q.rows_alloc * REC_SUBS * sizeof(uint4)));
     SFM_HIP(ctx, ctx->redo.reserve(((size_t)nq + 1) * 4));
     SFM_HIP(ctx, ctx->jobs.reserve(sizeof(KnnJob)));
     sfm_gpu_dmatch* out_dev = matches;
@@ -192,7 +192,7 @@ int knn_on_images(sfm_gpu_ctx* ctx, const ImageDev& q, const ImageDev& t, int k,
 // ---- working memory of sfm_gpu_knn_match_images_noalloc --------------------
 // One array per GPU the library runs on, part of the code object, so the entry
 // point never allocates.  Layout: sweep records | redo list | job descriptor.
-constexpr size_t NOALLOC_MAX_RECORDS = 524288;  // uint4 records: n_splits * padded query rows
+constexpr size_t NOALLOC_MAX_RECORDS = 1048576;  // uint4 records: n_splits * padded query rows * REC_SUBS
 constexpr int NOALLOC_MAX_QUERY = 32768;
 constexpr size_t NOALLOC_REDO_OFF = NOALLOC_MAX_RECORDS * sizeof(uint4);
 constexpr size_t NOALLOC_JOB_OFF = NOALLOC_REDO_OFF + ((size_t)NOALLOC_MAX_QUERY + 64) * 4;
@@ -429,11 +429,11 @@ int sfm_gpu_knn_match_images_noalloc(sfm_gpu_ctx* ctx, const sfm_gpu_image* quer
     if (!matches_dev || !counts_dev) return ctx->fail(SFM_GPU_ERR_ARG, "null output pointer");
     if (!ctx->static_scratch) return ctx->fail(SFM_GPU_ERR_HIP, "static working memory was not resolved");
     const KnnPlan plan = plan_knn(q.n, t.n, 1, -1);
-    const size_t records = (size_t)plan.n_splits * q.rows_alloc;
+    const size_t records = (size_t)plan.n_splits * q.rows_alloc * REC_SUBS;
     if (q.n > NOALLOC_MAX_QUERY || records > NOALLOC_MAX_RECORDS)
         return ctx->fail(SFM_GPU_ERR_CAPACITY,
                          "sfm_gpu_knn_match_images_noalloc: %d query rows x %d train parts = %zu records exceed "
-                         "the static working memory (at most %d query rows and %zu records)",
+                         "the static working memory (at most %d query rows and %zu records of 16 bytes)",
                          q.n, plan.n_splits, records, NOALLOC_MAX_QUERY, NOALLOC_MAX_RECORDS);
     SFM_HIP(ctx, hipSetDevice(ctx->device));
     unsigned char* base = (unsigned char*)ctx->static_scratch;
@@ -597,6 +597,37 @@ int sfm_gpu_debug_set_knn_variant(sfm_gpu_ctx* c, int variant)
 #endif
     if (variant >= 0 && variant % 16 > 5) return c->fail(SFM_GPU_ERR_UNSUPPORTED, "unknown sweep shape %d", variant % 16);
     c->knn_variant = variant < 0 ? -1 : variant;
+    return SFM_GPU_OK;
+}
+
+// Test hook: overwrites the LDS of every CU with a pattern, in stream order.
+int sfm_gpu_debug_poison_lds(sfm_gpu_ctx* ctx, uint32_t pattern)
+{
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, launch_lds_poison(ctx->stream, pattern));
+    return SFM_GPU_OK;
+}
+
+// Test hook: the first `bytes` of the context's sweep-record buffer.
+int sfm_gpu_debug_copy_records(sfm_gpu_ctx* ctx, void* out, size_t bytes)
+{
+    if (!ctx || !out || bytes > ctx->partial.cap) return SFM_GPU_ERR_ARG;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, hipMemcpyAsync(out, ctx->partial.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFM_GPU_OK;
+}
+
+// Timing build only: in-kernel stamps of the last 16x16 sweep (8 words per workgroup).
+int sfm_gpu_debug_sweep_stamps(sfm_gpu_ctx* ctx, uint64_t* out, int n_wg)
+{
+    if (!ctx || !out || n_wg < 0) return SFM_GPU_ERR_ARG;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const hipError_t e = read_sweep_stamps((unsigned long long*)out, n_wg);
+    if (e == hipErrorNotSupported) return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "stamps exist in the timing build only");
+    SFM_HIP(ctx, e);
     return SFM_GPU_OK;
 }
 

@@ -28,6 +28,9 @@ constexpr int ROW_ALIGN = 1024;
 // 0..255-valued rows: 23 bits, so (x << 9) | tile fits 32 bits.
 constexpr int KEY_OFFSET = 2080896;
 constexpr int PAD_CIN = 0x7FFFFF;  // padding rows rank behind every real row
+// Sweep records per (train part, query row): one per lane that holds the query in
+// the sweep (4 with 16x16 MFMAs, 2 of the 4 slots used with 32x32).
+constexpr int REC_SUBS = 4;
 
 // One image's descriptors as the distance kernel wants them.
 //   desc[r][d]  = value - 128 as int8 (byte = value ^ 0x80)
@@ -59,7 +62,7 @@ struct KnnJob {
     const int32_t* t_cin;
     const int32_t* q_qn;
     const int32_t* t_qn;
-    uint4* partial;       // [n_splits][q_rows_alloc] {best group, 2nd group, 3rd minimum, first tile | halves}
+    uint4* partial;       // [n_splits][q_rows_alloc][REC_SUBS] {best group, 2nd group, 3rd minimum, first unit}
     sfm_gpu_dmatch* out;  // [n_query][k]
     int32_t* counts;      // [n_query]
     int32_t* redo;        // [0] = count, [1..] = query rows needing the float-ranked pass
@@ -109,6 +112,10 @@ hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs
                                int n_splits, int k, int group_mode, double skip_ratio);
 hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_splits, int k,
                            double skip_ratio);
+// timing build only: the in-kernel stamps of the last 16x16 sweep, 8 words per workgroup
+hipError_t read_sweep_stamps(unsigned long long* out, int n_wg);
+// overwrites the LDS of every CU with a pattern (test hook)
+hipError_t launch_lds_poison(hipStream_t s, uint32_t pattern);
 hipError_t launch_mfma_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c);
 hipError_t launch_sqrt_probe(hipStream_t s, int32_t* mismatches);
 hipError_t launch_mfma16_layout_probe(hipStream_t s, const int8_t* a, const int8_t* b, int32_t* c);

@@ -30,3 +30,20 @@ def gpu_ctx():
     ctx = matcher.Context(0)
     yield ctx
     ctx.close()
+
+
+_poison_count = [0]
+
+
+@pytest.fixture(autouse=True)
+def _poison_lds_before_gpu_tests(request):
+    """Every GPU test starts with the LDS of every CU overwritten: a kernel that
+    skips a DMA or reads a stage too early must not find the right bytes there
+    because the previous test ran on the same data."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    ctx = request.getfixturevalue("gpu_ctx")
+    _poison_count[0] += 1
+    ctx.check(ctx._L.sfm_gpu_debug_poison_lds(ctx.handle, 0xA5A50000 + _poison_count[0]))
+    yield
