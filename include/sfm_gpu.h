@@ -45,6 +45,10 @@ extern "C" {
 #define SFM_GPU_RANSAC_ADAPTIVE 0 /* OpenCV loop: max_iters cap, iteration count shrinks   */
 #define SFM_GPU_RANSAC_FIXED 1    /* evaluate exactly n_hyp hypotheses, no early stop      */
 
+/* Largest n_hyp (fixed mode) / max_iters (adaptive mode) a call accepts;
+ * SFM_GPU_ERR_CAPACITY beyond. */
+#define SFM_GPU_MAX_HYPOTHESES (1 << 20)
+
 /* Layout-identical to cv::DMatch: the output rows of knnMatch can be
  * memcpy'd into std::vector<cv::DMatch>. */
 typedef struct sfm_gpu_dmatch {
@@ -114,7 +118,7 @@ int sfm_gpu_ratio_test(const sfm_gpu_dmatch* matches, const int32_t* counts, int
  *   K             host, 3x3 row-major camera matrix (ESSENTIAL only; may be
  *                 NULL for FUNDAMENTAL)
  *   prob          RANSAC confidence in (0,1)        (0.99 at main.cpp:224)
- *   threshold_px  inlier threshold in pixels        (1.0 at main.cpp:224)
+ *   threshold_px  inlier threshold in pixels, > 0   (1.0 at main.cpp:224)
  *   max_iters     iteration cap of the adaptive loop (OpenCV default 1000)
  *   mode          SFM_GPU_RANSAC_ADAPTIVE reproduces OpenCV's sequential,
  *                 self-shortening loop; SFM_GPU_RANSAC_FIXED solves exactly
@@ -132,11 +136,29 @@ int sfm_gpu_ratio_test(const sfm_gpu_dmatch* matches, const int32_t* counts, int
  *   n_inliers, iters_used   out, optional
  *   ok            out: 1 = a model was found, 0 = none (n < m, or no
  *                 hypothesis reached m inliers) — OpenCV returns an empty Mat
+ * n == m (5 or 7): no RANSAC, one direct solve, mask all ones, `model` = the
+ * first candidate (all of them: sfm_gpu_ransac_candidates).  FUNDAMENTAL with
+ * 8 <= n <= 14 in ADAPTIVE mode returns SFM_GPU_ERR_UNSUPPORTED:
+ * cv::findFundamentalMat switches to LMedS there, which is not on this path.
  */
 int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int n,
                    const double* K, int model, double prob, double threshold_px, int max_iters,
                    int mode, const int32_t* sample_table, int n_hyp, uint8_t* mask,
                    double* model_out, int32_t* n_inliers, int32_t* iters_used, int32_t* ok);
+
+/*
+ * Every candidate model of the minimal sample that won the last sfm_gpu_ransac
+ * call on this context, in solver order (at most 10 for the five-point solver,
+ * 3 for the seven-point solver).  With n == 5 (or 7) correspondences
+ * cv::findEssentialMat / cv::findFundamentalMat run no RANSAC and return all
+ * candidates stacked in one 3k x 3 matrix (main.cpp:224 would receive that
+ * matrix); sfm_gpu_ransac then puts the first one into `model` and this call
+ * delivers the whole stack.
+ *   models_out   host, capacity x 9 doubles
+ *   n_models     out; SFM_GPU_ERR_CAPACITY (and *n_models set) when capacity is
+ *                too small
+ */
+int sfm_gpu_ransac_candidates(sfm_gpu_ctx* ctx, double* models_out, int capacity, int32_t* n_models);
 
 /* ---- pose recovery: replaces main.cpp:420 ----------------------------- */
 
@@ -290,9 +312,8 @@ typedef struct sfm_gpu_match_params {
  *                 selectMatches occupy [p*match_capacity, +n_inliers[p])
  *   match_capacity  records reserved per pair (>= the largest query image when
  *                 inlier_matches != NULL)
- * Images without keypoints can only be used with inlier_matches == NULL and
- * mode FIXED on synthetic geometry supplied separately; normally keypoints are
- * required.
+ * Every image named by a pair must carry keypoints (SFM_GPU_ERR_ARG otherwise):
+ * they are the points RANSAC runs on.
  */
 int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images, const int32_t* pairs,
                         int n_pairs, const sfm_gpu_match_params* params, int32_t* n_good,

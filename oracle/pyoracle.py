@@ -219,6 +219,16 @@ def ransac(pts1, pts2, K=None, model=MODEL_ESSENTIAL, prob=0.99, threshold=1.0, 
                 counts=counts)
 
 
+def ransac_direct_models():
+    """Candidates of the calling thread's last n == m ransac() call, [k, 3, 3]."""
+    out = np.zeros((10, 3, 3), dtype=np.float64)
+    L = lib()
+    L.oracle_ransac_direct_models.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.oracle_ransac_direct_models.restype = ctypes.c_int
+    k = L.oracle_ransac_direct_models(_p(out), 10)
+    return out[:max(k, 0)].copy()
+
+
 def svd3(A):
     A = np.ascontiguousarray(A, dtype=np.float64)
     U = np.zeros((3, 3)); S = np.zeros(3); V = np.zeros((3, 3))

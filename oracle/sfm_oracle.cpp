@@ -1046,6 +1046,17 @@ double oracle_normalize_points(const double* pts_px, int n, const double* K, dou
     return threshold_px / ((fx + fy) / 2);
 }
 
+// candidates of the last direct (n == m) solve on this thread
+static thread_local int g_direct_n = 0;
+static thread_local double g_direct_models[10 * 9];
+
+int oracle_ransac_direct_models(double* models_out, int capacity)
+{
+    if (g_direct_n > capacity) return -1;
+    std::memcpy(models_out, g_direct_models, (size_t)g_direct_n * 9 * sizeof(double));
+    return g_direct_n;
+}
+
 int oracle_ransac(int model_kind, const double* pts1, const double* pts2, int n, const double* K,
                   double prob, double threshold_px, int max_iters, int fixed_count,
                   const int32_t* sample_table, uint8_t* mask, double* model_out,
@@ -1101,7 +1112,10 @@ int oracle_ransac(int model_kind, const double* pts1, const double* pts2, int n,
         for (int i = 0; i < m; i++) idx[i] = i;
         int nm = solve(idx, models);
         if (nm <= 0) return 0;
-        // OpenCV returns every candidate stacked; this interface reports the first
+        // OpenCV returns every candidate stacked; model_out takes the first, the
+        // whole stack goes to direct_models_out when the caller wants it
+        g_direct_n = nm;
+        std::memcpy(g_direct_models, models, (size_t)nm * 9 * sizeof(double));
         std::memcpy(model_out, models, 9 * sizeof(double));
         std::memset(mask, 1, n);
         if (n_inliers) *n_inliers = n;

@@ -131,6 +131,12 @@ int oracle_ransac(int model_kind, const double* pts1, const double* pts2, int n,
                   uint8_t* mask, double* model_out, int32_t* n_inliers,
                   int32_t* iters_used, int32_t* hyp_counts);
 
+/* With n == m points cv::findEssentialMat / findFundamentalMat return every
+ * candidate of the one direct solve stacked (3k x 3); oracle_ransac reports the
+ * first in model_out, this returns all k of the calling thread's last such call
+ * (capacity in models; -1 when it is too small). */
+int oracle_ransac_direct_models(double* models_out, int capacity);
+
 /* 3x3 singular value decomposition A = U diag(S) V^T by one-sided Jacobi
  * rotations (row-major, |S| descending, U[:,2] = U[:,0] x U[:,1] with S[2]
  * carrying the sign).  Returns 1, or 0 when A has rank < 2. */

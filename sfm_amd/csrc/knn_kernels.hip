@@ -503,6 +503,9 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
     uint32_t m1[QB], m2[QB], m3[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) m1[qb] = m2[qb] = m3[qb] = 0xFFFFFFFFu;
+#ifdef SFM_EXP_PRIO
+    if (WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // stage image in LDS and its DMA: as in the 32x32 kernel
     const int dma_r = lane >> 3;
@@ -1274,6 +1277,9 @@ KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant
             splits = sp;
         }
     }
+#ifdef SFM_GPU_TIMING_BUILD
+    if (const char* e = getenv("SFM_KNN_SPLITS")) splits = std::max(s_min, std::min(atoi(e), std::max(t_chunks, 1)));  // experiments
+#endif
     p.n_splits = splits;
     p.chunks_per_split = (t_chunks + splits - 1) / splits;
     if (p.chunks_per_split < 1) p.chunks_per_split = 1;

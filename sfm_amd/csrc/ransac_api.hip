@@ -70,7 +70,6 @@ void carve_ransac(RansacProb& pb, char* base, int cap, int hyp_cap, int m)
     pb.x2 = (double*)take((size_t)cap * 16);
     pb.f1 = (float*)take((size_t)cap * 8);
     pb.f2 = (float*)take((size_t)cap * 8);
-    pb.cap_pad = (cap + 2) & ~1;
     pb.soa = (float*)take(((size_t)cap + 7) / 4 * 64);
     pb.table = (int32_t*)take((size_t)hyp_cap * m * 4);
     pb.models = (double*)take((size_t)hyp_cap * 90 * 8);
@@ -90,6 +89,20 @@ int fill_params(sfm_gpu_ctx* ctx, RansacProb& pb, const RansacParams& rp)
     if (!(rp.prob > 0 && rp.prob < 1)) return ctx->fail(SFM_GPU_ERR_ARG, "prob must be in (0,1)");
     if (rp.mode == SFM_GPU_RANSAC_FIXED && rp.n_hyp < 1)
         return ctx->fail(SFM_GPU_ERR_ARG, "n_hyp must be >= 1 in fixed mode");
+    if (rp.mode == SFM_GPU_RANSAC_FIXED && rp.n_hyp > SFM_GPU_MAX_HYPOTHESES)
+        return ctx->fail(SFM_GPU_ERR_CAPACITY, "n_hyp %d exceeds SFM_GPU_MAX_HYPOTHESES (%d)", rp.n_hyp,
+                         SFM_GPU_MAX_HYPOTHESES);
+    if (rp.mode == SFM_GPU_RANSAC_ADAPTIVE && rp.max_iters > SFM_GPU_MAX_HYPOTHESES)
+        return ctx->fail(SFM_GPU_ERR_CAPACITY, "max_iters %d exceeds SFM_GPU_MAX_HYPOTHESES (%d)", rp.max_iters,
+                         SFM_GPU_MAX_HYPOTHESES);
+    if (!(rp.threshold_px > 0) || !std::isfinite(rp.threshold_px))
+        return ctx->fail(SFM_GPU_ERR_ARG, "threshold_px must be positive and finite");
+    if (rp.model == SFM_GPU_MODEL_ESSENTIAL) {
+        const double f = (rp.K[0] + rp.K[4]) / 2;
+        if (!std::isfinite(f) || f == 0.0 || rp.K[0] == 0.0 || rp.K[4] == 0.0 || !std::isfinite(rp.K[2]) ||
+            !std::isfinite(rp.K[5]))
+            return ctx->fail(SFM_GPU_ERR_ARG, "camera matrix needs finite, non-zero focal lengths");
+    }
     pb.model = rp.model;
     pb.m = rp.model == SFM_GPU_MODEL_ESSENTIAL ? 5 : 7;
     double thr = rp.threshold_px;
@@ -366,7 +379,14 @@ int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int
     int rc = fill_params(ctx, probs[0], rp);
     if (rc) return rc;
     const int m = probs[0].m;
+    ctx->last_hyp = -1;
     if (n < m) return SFM_GPU_OK;  // OpenCV: returns false, mask untouched
+    // cv::findFundamentalMat runs RANSAC only from 15 points on: 8..14 points go to
+    // LMedS, which is not on this path.  (7 points: one direct solve, as here.  The
+    // fixed-count mode is a benchmark mode of this library and takes any n >= 7.)
+    if (model == SFM_GPU_MODEL_FUNDAMENTAL && mode == SFM_GPU_RANSAC_ADAPTIVE && n > m && n < 15)
+        return ctx->fail(SFM_GPU_ERR_UNSUPPORTED,
+                         "fundamental matrix from %d points: OpenCV uses LMedS for 8..14 points, not RANSAC", n);
     if (sample_table && n > m)
         for (long long i = 0; i < (long long)n_hyp * m; ++i)
             if (sample_table[i] < 0 || sample_table[i] >= n)
@@ -399,6 +419,7 @@ int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int
     rc = ransac_batch(ctx, probs, n, hyp_cap, rp, (sample_table && n > m) ? sample_table : nullptr, results, true);
     if (rc) return rc;
     *ok = results[R_OK];
+    ctx->last_hyp = results[R_OK] ? results[R_HYP] : -1;
     if (iters_used) *iters_used = results[R_ITERS];
     if (results[R_OK]) {
         if (n_inliers) *n_inliers = results[R_NINL];
@@ -406,6 +427,28 @@ int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int
         ctx->hint_points = n;
         SFM_HIP(ctx, hipMemcpyAsync(mask, probs[0].mask, n, hipMemcpyDeviceToHost, ctx->stream));
         SFM_HIP(ctx, hipMemcpyAsync(model_out, probs[0].model_out, 72, hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_ransac_candidates(sfm_gpu_ctx* ctx, double* models_out, int capacity, int32_t* n_models)
+{
+    if (!ctx || !n_models || capacity < 0 || (capacity > 0 && !models_out)) return SFM_GPU_ERR_ARG;
+    *n_models = 0;
+    if (ctx->last_hyp < 0 || !ctx->dbg_models || ctx->last_hyp >= ctx->dbg_hyp_cap)
+        return ctx->fail(SFM_GPU_ERR_ARG, "the last sfm_gpu_ransac call on this context found no model");
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t nm = 0;
+    SFM_HIP(ctx, hipMemcpyAsync(&nm, ctx->dbg_nmodels + ctx->last_hyp, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (nm < 0 || nm > MAX_MODELS) return ctx->fail(SFM_GPU_ERR_HIP, "corrupt candidate count %d", nm);
+    *n_models = nm;
+    if (nm > capacity)
+        return ctx->fail(SFM_GPU_ERR_CAPACITY, "%d candidate models, room for %d", nm, capacity);
+    if (nm > 0) {
+        SFM_HIP(ctx, hipMemcpyAsync(models_out, ctx->dbg_models + (size_t)ctx->last_hyp * MAX_MODELS * 9,
+                                    (size_t)nm * 72, hipMemcpyDeviceToHost, ctx->stream));
         SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return SFM_GPU_OK;
@@ -441,6 +484,8 @@ static int mp_plan(sfm_gpu_ctx* ctx, MpPlan& pl, sfm_gpu_image* const* images, i
     for (int p = 0; p < 2 * n_pairs; ++p)
         if (pairs[p] < 0 || pairs[p] >= n_images)
             return ctx->fail(SFM_GPU_ERR_ARG, "pair %d names image %d of %d", p / 2, pairs[p], n_images);
+    if (!std::isfinite(params->ratio))
+        return ctx->fail(SFM_GPU_ERR_ARG, "ratio must be finite");
     RansacParams& rp = pl.rp;
     rp.model = params->model;
     rp.mode = params->mode;

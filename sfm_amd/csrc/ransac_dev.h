@@ -34,7 +34,7 @@ struct RansacProb {
     double* x2;
     float* f1;             // [cap][2] float32 pixels (fundamental model)
     float* f2;
-    float* soa;            // [4][cap_pad] float32 planes X1, Y1, X2, Y2 of x1/x2
+    float* soa;            // [ceil(cap/4)][X1 Y1 X2 Y2][4] float32 copies of x1/x2, four points per 64-byte block
     int32_t* table;        // [hyp_cap][m]
     double* models;        // [hyp_cap][MAX_MODELS][9]
     int32_t* nmodels;      // [hyp_cap]
@@ -48,7 +48,6 @@ struct RansacProb {
     float tf;              // (float)(threshold^2), threshold already scaled
     int32_t model;         // SFM_GPU_MODEL_*
     int32_t m;             // minimal sample size: 5 or 7
-    int32_t cap_pad;       // plane stride of soa (even, >= cap)
 };
 
 // What RANSAC keeps of correspondence i, given its pixel coordinates in both

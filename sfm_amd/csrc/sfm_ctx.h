@@ -190,6 +190,7 @@ struct sfm_gpu_ctx {
     const int32_t* dbg_nmodels = nullptr;
     const double* dbg_models = nullptr;
     int dbg_hyp_cap = 0, dbg_m = 0;
+    int last_hyp = -1;  // winning sample row of the last sfm_gpu_ransac call, -1: none
 
     bool profiling = false;
     std::string profile_only;  // empty: every named kernel is timed

@@ -330,13 +330,14 @@ int sfm_gpu_knn_match(sfm_gpu_ctx* ctx, const void* query, int n_query, size_t q
     if (rc) return rc;
     rc = prepare_image(ctx, ctx->tmp_t, ctx->raw_t, train, n_train, train_step, dtype, false, false);
     if (rc) return rc;
+    // both conversions have been waited for (prepare_image synchronises): read the
+    // validation flag now, so that no copy into this frame is in flight on any path out
     int32_t flag = 0;
     SFM_HIP(ctx, hipMemcpyAsync(&flag, ctx->flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    rc = knn_on_images(ctx, ctx->tmp_q.d, ctx->tmp_t.d, k, matches, counts, false);
-    if (rc) return rc;
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (flag)
         return ctx->fail(SFM_GPU_ERR_NOT_U8, "descriptor values must be integers in 0..255");
-    return SFM_GPU_OK;
+    return knn_on_images(ctx, ctx->tmp_q.d, ctx->tmp_t.d, k, matches, counts, false);
 }
 
 int sfm_gpu_ratio_test(const sfm_gpu_dmatch* matches, const int32_t* counts, int n_query, int k,
@@ -363,9 +364,9 @@ int sfm_gpu_image_create(sfm_gpu_ctx* ctx, const void* desc, int n, size_t step,
     if (n >= (1 << 18)) return ctx->fail(SFM_GPU_ERR_TOO_MANY, "image rows %d >= 2^18", n);
     if (n > 0 && !desc) return ctx->fail(SFM_GPU_ERR_ARG, "null descriptor pointer");
     SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, hipMemsetAsync(ctx->flags.p, 0, 4, ctx->stream));
     ImageHolder* h = new (std::nothrow) ImageHolder();
     if (!h) return ctx->fail(SFM_GPU_ERR_NOMEM, "host allocation failed");
-    SFM_HIP(ctx, hipMemsetAsync(ctx->flags.p, 0, 4, ctx->stream));
     rc = prepare_image(ctx, h->st, ctx->raw_q, desc, n, step, dtype, desc_on_device != 0,
                        keypoints_xy != nullptr);
     if (rc == SFM_GPU_OK && keypoints_xy && n > 0) {
@@ -514,6 +515,8 @@ int sfm_gpu_image_wrap(sfm_gpu_ctx* ctx, const void* packed_dev, int n, int has_
                        sfm_gpu_image** out)
 {
     if (!ctx || !out || !packed_dev || n < 0) return SFM_GPU_ERR_ARG;
+    *out = nullptr;
+    if (n >= (1 << 18)) return ctx->fail(SFM_GPU_ERR_TOO_MANY, "image rows %d >= 2^18", n);
     ImageHolder* h = new (std::nothrow) ImageHolder();
     if (!h) return ctx->fail(SFM_GPU_ERR_NOMEM, "host allocation failed");
     h->img.d = image_layout((void*)packed_dev, n);

@@ -151,6 +151,16 @@ def _ransac(ctx, pts1, pts2, K, model, prob, threshold, max_iters, mode, sample_
     return dict(ok=ok.value, model=out, mask=mask, n_inliers=n_inl.value, iters=iters.value)
 
 
+def ransac_candidates(ctx):
+    """All candidate models ([k, 3, 3]) of the minimal sample that won the last
+    findEssentialMat / findFundamentalMat call on ctx; with exactly 5 (7) points
+    this is the stack of solutions OpenCV returns as one 3k x 3 matrix."""
+    out = np.zeros((10, 3, 3), dtype=np.float64)
+    n = ctypes.c_int32(0)
+    ctx.check(ctx._L.sfm_gpu_ransac_candidates(ctx.handle, ptr(out), 10, ctypes.byref(n)))
+    return out[:n.value].copy()
+
+
 def findEssentialMat(ctx, points1, points2, cameraMatrix, method=FM_RANSAC, prob=0.999,
                      threshold=1.0, maxIters=1000, mask=None, mode=RANSAC_ADAPTIVE,
                      sample_table=None, n_hyp=0):

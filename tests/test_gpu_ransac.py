@@ -263,3 +263,64 @@ def test_first_stage_size_follows_history_but_not_the_result(gpu_ctx, oracle):
                                                 mode=matcher.RANSAC_FIXED, n_hyp=192)
         assert (mask == want[name][0]).all() and r["n_inliers"] == want[name][2]
         assert (np.asarray(F) == want[name][1]).all()
+
+
+def test_minimal_point_counts_return_every_candidate(gpu_ctx, oracle):
+    """n == 5 (essential) and n == 7 (fundamental): OpenCV runs no RANSAC and
+    returns every candidate of the one direct solve stacked; the first goes to
+    the model output, sfm_gpu_ransac_candidates delivers the stack."""
+    for seed in (1, 2, 3):
+        p1, p2, _, _ = synth.two_view(7, seed, inlier_frac=1.0, noise_px=0.3)
+        E, mask, r = matcher.findEssentialMat(gpu_ctx, p1[:5], p2[:5], synth.REF_K, prob=0.99)
+        o = oracle.ransac(p1[:5], p2[:5], synth.REF_K, prob=0.99)
+        want = oracle.ransac_direct_models()
+        got = matcher.ransac_candidates(gpu_ctx)
+        assert r["ok"] == o["ok"] == 1 and mask.tolist() == [1] * 5
+        assert got.shape == want.shape and got.shape[0] >= 1
+        assert (got == want).all() and (got[0] == np.asarray(E)).all()
+        F, mask, r = matcher.findFundamentalMat(gpu_ctx, p1, p2, ransacReprojThreshold=3.0)
+        o = oracle.ransac(p1, p2, None, model=1, prob=0.99, threshold=3.0)
+        want = oracle.ransac_direct_models()
+        got = matcher.ransac_candidates(gpu_ctx)
+        assert r["ok"] == o["ok"] == 1 and mask.tolist() == [1] * 7
+        assert got.shape == want.shape and 1 <= got.shape[0] <= 3
+        assert (got == want).all() and (got[0] == np.asarray(F)).all()
+    # after an ordinary run: the candidates of the winning sample, the model among them
+    p1, p2, _, _ = synth.two_view(400, 9, inlier_frac=0.8)
+    E, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, prob=0.99)
+    got = matcher.ransac_candidates(gpu_ctx)
+    assert any((g == np.asarray(E)).all() for g in got)
+
+
+def test_fundamental_between_8_and_14_points_is_refused(gpu_ctx):
+    """cv::findFundamentalMat(FM_RANSAC) uses LMedS for 8..14 points: not this path."""
+    from sfm_amd import _lib
+    p1, p2, _, _ = synth.two_view(20, 4, inlier_frac=1.0)
+    for n in (8, 11, 14):
+        with pytest.raises(matcher.SfmGpuError) as e:
+            matcher.findFundamentalMat(gpu_ctx, p1[:n], p2[:n])
+        assert e.value.code == _lib.ERR_UNSUPPORTED
+        # the fixed-count benchmark mode has no OpenCV counterpart and takes any n >= 7
+        F, mask, r = matcher.findFundamentalMat(gpu_ctx, p1[:n], p2[:n], mode=matcher.RANSAC_FIXED, n_hyp=16)
+        assert r["ok"] in (0, 1)
+    F, mask, r = matcher.findFundamentalMat(gpu_ctx, p1[:15], p2[:15])
+    assert r["ok"] == 1
+
+
+def test_bad_parameters_are_rejected(gpu_ctx):
+    from sfm_amd import _lib
+    p1, p2, _, _ = synth.two_view(50, 5, inlier_frac=1.0)
+    K0 = synth.REF_K.copy()
+    K0[0, 0] = K0[1, 1] = 0.0
+    bad = [dict(threshold=0.0), dict(threshold=-1.0), dict(threshold=float("nan")), dict(threshold=float("inf")),
+           dict(prob=1.0), dict(prob=float("nan"))]
+    for kw in bad:
+        with pytest.raises(matcher.SfmGpuError) as e:
+            matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, **kw)
+        assert e.value.code == _lib.ERR_ARG, kw
+    with pytest.raises(matcher.SfmGpuError) as e:
+        matcher.findEssentialMat(gpu_ctx, p1, p2, K0)
+    assert e.value.code == _lib.ERR_ARG
+    with pytest.raises(matcher.SfmGpuError) as e:
+        matcher.findEssentialMat(gpu_ctx, p1, p2, synth.REF_K, mode=matcher.RANSAC_FIXED, n_hyp=(1 << 20) + 1)
+    assert e.value.code == _lib.ERR_CAPACITY
