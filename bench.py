@@ -13,13 +13,26 @@ own batch (pairs are independent units: weak scaling, no data-path collective);
 ranks synchronise with a barrier on both sides of the timed region and the
 slowest rank's time is used.
 
+Ranks: one process per GPU.  Under a launcher (WORLD_SIZE set, e.g.
+torch.distributed.run) this process is one rank.  Started plainly with
+--gpus N > 1 it starts N fresh child processes itself, before anything touches
+a GPU, one device each, and passes rank 0's line through; `n_gpus` in the line
+is the number of ranks that joined the process group.
+
 Prints one JSON line (rank 0).  `roofline` prices the distance kernel
-(knn2_mfma) against the dense int8 MFMA peak; `cpu_baseline` is the CPU oracle
-timed on this host's cores on one full pair of the same workload.
+(knn2_mfma) against the dense int8 MFMA peak; `roofline_secondary` the RANSAC
+scoring pass; `configs2` one 32768 x 32768 pair with 4096 five-point
+hypotheses; `allpairs` the exhaustive matching of 64 views x 20 000 descriptors
+sharded over the ranks (strong scaling: all-gather of the prepared images,
+dealt pair list, all-reduce of the count matrices); `cpu_baseline` is the CPU
+oracle timed on this host's cores on full pairs of the same workload.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -56,8 +69,8 @@ def cpu_baseline(descs, kps, n_hyp, threads, n_pairs):
         p1 = kps[2 * p][good["queryIdx"]].astype(np.float64)
         p2 = kps[2 * p + 1][good["trainIdx"]].astype(np.float64)
         t1 = time.perf_counter()
-        r = po.ransac(p1, p2, None, model=po.MODEL_FUNDAMENTAL, prob=0.99, threshold=3.0,
-                      fixed_count=n_hyp)
+        r = po.ransac_fixed_mt(p1, p2, None, model=po.MODEL_FUNDAMENTAL, threshold=3.0, fixed_count=n_hyp,
+                               nthreads=threads)
         t2 = time.perf_counter()
         t_knn += t1 - t0
         t_ransac += t2 - t1
@@ -65,6 +78,49 @@ def cpu_baseline(descs, kps, n_hyp, threads, n_pairs):
         n_inl += int(r["n_inliers"])
     return dict(seconds=t_knn + t_ransac, knn_seconds=t_knn, ransac_seconds=t_ransac, n_pairs=n_pairs,
                 n_good=n_good / n_pairs, n_inliers=n_inl / n_pairs)
+
+
+def host_threads():
+    """Threads for the CPU leg: the cores this process may run on, never more than
+    the thread budget the environment sets (OMP_NUM_THREADS on a shared box)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        n = min(n, int(os.environ["OMP_NUM_THREADS"]))
+    except (KeyError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def spawn_ranks(n):
+    """Starts n fresh rank processes of this script (nothing in this process has
+    touched a GPU), waits for them and returns the largest exit code.  Rank 0
+    inherits stdout, so its JSON line is this command's output."""
+    import torch
+    backend = os.environ.get("SFM_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and not os.environ.get("SFM_BENCH_DRYRUN"):
+        have = torch.cuda.device_count()  # counting devices does not initialise the runtime
+        if have < n:
+            raise SystemExit("--gpus %d needs %d GPUs, %d visible (SFM_BENCH_BACKEND=gloo rehearses the "
+                             "control flow with ranks sharing devices)" % (n, n, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def source_sha(path):
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
 
 
 def main():
@@ -94,17 +150,45 @@ def main():
                          "kernels never overlap and their durations are their own)")
     ap.add_argument("--desc-u8", action="store_true",
                     help="descriptors arrive as CV_8U instead of cv::SIFT's CV_32F (not the headline configuration)")
+    ap.add_argument("--no-configs2", action="store_true", help="skip the 32768 x 32768 pair block")
+    ap.add_argument("--no-allpairs", action="store_true", help="skip the exhaustive-matching block")
+    ap.add_argument("--allpairs-views", type=int, default=64)
+    ap.add_argument("--allpairs-desc", type=int, default=20000)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # one process per GPU: start the ranks before anything here touches a GPU
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
-    from sfm_amd import matcher
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if os.environ.get("SFM_BENCH_DRYRUN"):
+        # control flow only (no GPU work): rendezvous, barrier, reduction, one line
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            joined = dist.get_world_size()
+            assert t.item() == world
+        else:
+            joined = 1
+        if rank == 0:
+            print(json.dumps({"metric": "matched image pairs/sec (8k x 8k SIFT, k=2+RANSAC)", "value": 0.0,
+                              "unit": "pairs/s", "n_gpus": joined, "steps": args.steps, "warmup": args.warmup,
+                              "dry_run": True}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    from sfm_amd import matcher
     # SFM_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with
     # fewer GPUs than ranks (ranks then share devices); the real run is RCCL.
     backend = os.environ.get("SFM_BENCH_BACKEND", "nccl")
@@ -309,7 +393,9 @@ def main():
         tctx.profile_enable(True)
         tctx.check(tctx._L.sfm_gpu_debug_set_knn_variant(
             tctx.handle, (args.knn_variant if args.knn_variant >= 0 else 4) + 16 * 7))
-        for _ in range(3):
+        for it in range(5):
+            if it == 2:   # the first calls load the timing library's code objects and size its workspaces
+                tctx.profile_reset()
             matcher.match_pairs(tctx, timages, pairs, None, ratio=0.7, model=matcher.MODEL_FUNDAMENTAL,
                                 mode=matcher.RANSAC_FIXED, prob=0.99, threshold=3.0, n_hyp=nh)
         tctx.synchronize()
@@ -317,11 +403,115 @@ def main():
         for im in timages:
             im.close()
         tctx.close()
+    ctx.profile_select(None)
+    ctx.profile_enable(False)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    joined = dist.get_world_size() if world > 1 else 1
+
+    # ---- BASELINE configs[2]: one 32768 x 32768 pair + essential RANSAC, 4096 hypotheses
+    # (outside the timed region; rank 0 of a single-GPU run only)
+    configs2 = None
+    if rank == 0 and world == 1 and not args.no_configs2:
+        from sfm_amd import synth
+        n2, nh2 = 32768, 4096
+        Q2, T2, planted2 = synth.planted_pair(n2, n2, 1101, 1102, 1103)
+        kq2, kt2 = synth.keypoints_for_pair(n2, n2, planted2, 2101, wrong_frac=args.wrong_frac)
+        with torch.cuda.stream(stream):
+            d2 = torch.from_numpy(np.stack([Q2, T2])).cuda()
+            k2 = torch.from_numpy(np.stack([kq2, kt2])).cuda()
+            blk2 = matcher.image_packed_bytes(n2)
+            pk2 = torch.empty((2, blk2), dtype=torch.uint8, device="cuda")
+        stream.synchronize()
+        matcher.prepare_many(ctx, [d2[i].data_ptr() for i in range(2)], [n2, n2], 512, matcher.DESC_F32,
+                             [k2[i].data_ptr() for i in range(2)], [pk2[i].data_ptr() for i in range(2)])
+        matcher.check_inputs(ctx)
+        im2 = [matcher.WrappedImage(ctx, pk2[i].data_ptr(), n2) for i in range(2)]
+        one = np.array([[0, 1]], np.int32)
+        kw2 = dict(ratio=0.7, model=matcher.MODEL_ESSENTIAL, mode=matcher.RANSAC_FIXED, prob=0.99, threshold=1.0,
+                   n_hyp=nh2)
+        from sfm_amd import synth as _synth
+        for _ in range(3):
+            g2, i2 = matcher.match_pairs(ctx, im2, one, _synth.REF_K, **kw2)
+        ctx.profile_select(None)
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        reps2 = 10
+        t2 = time.perf_counter()
+        for _ in range(reps2):
+            g2, i2 = matcher.match_pairs(ctx, im2, one, _synth.REF_K, **kw2)
+        ctx.synchronize()
+        wall2 = (time.perf_counter() - t2) / reps2
+        k2us = {}
+        for name in ("knn2_mfma", "knn_finalize", "ransac_solve", "ransac_score", "ransac_select"):
+            ms, cnt = ctx.profile_query(name)
+            if cnt:
+                k2us[name] = round(ms / cnt * 1e3, 2)
+        ctx.profile_enable(False)
+        ops2 = 2.0 * n2 * n2 * 128
+        configs2 = {
+            "workload": "configs[2]: one pair of %dx%d descriptors, kNN k=2 + ratio 0.7 + five-point essential "
+                        "RANSAC %d hyps (fixed count)" % (n2, n2, nh2),
+            "knn2_mfma_us": k2us.get("knn2_mfma"),
+            "knn2_mfma_frac_of_int8_peak": round(ops2 / (k2us["knn2_mfma"] * 1e-6) / 1e12 / INT8_DENSE_PEAK_TOPS, 4)
+            if k2us.get("knn2_mfma") else None,
+            "five_point_solve_us": k2us.get("ransac_solve"),
+            "scoring_us": k2us.get("ransac_score"),
+            "neighbour_extraction_us": k2us.get("knn_finalize"),
+            "ms_per_pair_host_clock": round(wall2 * 1e3, 3),
+            "n_good": int(g2[0]), "n_inliers": int(i2[0]),
+            "what": "HIP events around each launch of the one-pair call (one sweep launch of 512 workgroups), "
+                    "average of %d calls, measured after the timed region" % reps2,
+        }
+        for im in im2:
+            im.close()
+        del d2, k2, pk2
+
+    # ---- BASELINE configs[3]: exhaustive matching of V views, sharded over the ranks (strong scaling)
+    allp = None
+    if not args.no_allpairs:
+        from sfm_amd import allpairs, synth
+        V, nd = args.allpairs_views, args.allpairs_desc
+        lo, hi = allpairs.owned_range(V, world, rank)
+        descs_v, kps_v, _ = synth.image_sequence(hi, nd, 4242, shared=0.4)   # images lo..hi-1 are this rank's
+        with torch.cuda.stream(stream):
+            local = [(torch.from_numpy(descs_v[i]).cuda(), torch.from_numpy(kps_v[i]).cuda()) for i in range(lo, hi)]
+        stream.synchronize()
+        del descs_v, kps_v
+        be = allpairs.GpuBackend(ctx, K=synth.REF_K, model=matcher.MODEL_ESSENTIAL, mode=matcher.RANSAC_ADAPTIVE,
+                                 prob=0.99, threshold=1.0, max_iters=1000)
+        dev = torch.device("cuda", local_rank)
+        best = None
+        with torch.cuda.stream(stream):
+            for rep in range(3):   # the first run sizes the workspaces
+                fence()
+                t3 = time.perf_counter()
+                ap_pairs, ap_good, ap_inl, ap_stats = allpairs.match_all_pairs(local, V, be, mode="all", device=dev,
+                                                                             return_stats=True)
+                fence()
+                dt3 = time.perf_counter() - t3
+                if world > 1:
+                    tt = torch.tensor([dt3], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt3 = float(tt.item())
+                if rep > 0:
+                    best = dt3 if best is None else min(best, dt3)
+        adj = [int(ap_inl[i, i + 1]) for i in range(V - 1)]
+        allp = {
+            "workload": "configs[3]: %d views x %d descriptors, all %d pairs, kNN k=2 + ratio 0.7 + essential RANSAC "
+                        "(adaptive, prob 0.99, 1 px), descriptors resident in HBM as float32" % (V, nd, len(ap_pairs)),
+            "scaling": "strong", "n_gpus": joined, "pairs": int(len(ap_pairs)),
+            "seconds": round(best, 5), "pairs_per_s": round(len(ap_pairs) / best, 1),
+            "includes": "descriptor conversion where the images live, all-gather of the prepared images, dealt pair "
+                        "list, matching, all-reduce of the V x V count matrices (max over ranks, best of 2 runs)",
+            "gathered_bytes_per_rank": ap_stats["gathered_bytes"], "collective_backend": backend if world > 1 else None,
+            "inliers_neighbouring_views_min_max": [min(adj), max(adj)] if adj else None,
+            "inliers_farthest_pair": int(ap_inl[0, V - 1]) if V > 1 else None,
+        }
+        del local
 
     if rank == 0:
         total_pairs = B * args.steps * world
@@ -335,7 +525,10 @@ def main():
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                if pmc.get("pairs_per_launch") == B and pmc.get("n_desc") == n:
+                # counters are only quoted for the kernel source they were collected on
+                same_kernel = pmc.get("kernel_source_sha256") == source_sha(
+                    os.path.join(ROOT, "sfm_amd", "csrc", "knn_kernels.hip"))
+                if same_kernel and pmc.get("pairs_per_launch") == B and pmc.get("n_desc") == n:
                     traffic = pmc.get("hbm_bytes_per_launch")
                     pipe_busy = pmc.get("mfma_pipe_busy_frac")
             except Exception:
@@ -344,7 +537,7 @@ def main():
             "metric": "matched image pairs/sec (8k x 8k SIFT, k=2+RANSAC)",
             "value": round(value, 2),
             "unit": "pairs/s",
-            "n_gpus": world,
+            "n_gpus": joined,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -392,18 +585,48 @@ def main():
             "kernels_outside_timed_region": kern,
             "two_unordered_streams_outside_timed_region": probe,
         }
+        sc = kern.get("ransac_score")
+        if sc:
+            # RANSAC scoring, second kernel of the step: every candidate model against every
+            # ratio-test survivor.  Algorithmic work = the exhaustive loop's (models x points
+            # tests of ~40 double-precision flops, models*72 B + points*32 B read once); the
+            # kernel settles most tests in float32 and drops models that cannot win, so it
+            # does less than that.  Points stay in L2 / the scalar cache: the bound is vector
+            # issue, not HBM.
+            n_models = 3.0 * nh * 0.83        # seven-point solver: up to 3 real roots, ~2.5 on average
+            tests = B * n_models * float(np.mean(n_good))
+            step_us = sc["avg_us"] * sc["launches"] / 2.0   # launches counted over the two extra steps
+            bytes_alg = B * (n_models * 72.0 + float(np.mean(n_good)) * 32.0)
+            out["roofline_secondary"] = {
+                "kernel": "ransac_score", "bound": "vector issue (packed float32 filter, double precision for "
+                                                   "the ~1 % of tests the filter cannot settle)",
+                "us_per_step": round(step_us, 2),
+                "algorithmic_tests_per_step": round(tests),
+                "algorithmic_gtests_per_s": round(tests / (step_us * 1e-6) / 1e9, 1),
+                "equivalent_fp64_tflops_at_40_flops_per_test": round(tests * 40.0 / (step_us * 1e-6) / 1e12, 1),
+                "fp64_vector_peak_tflops": 78.6,
+                "hbm": {"algorithmic_bytes_per_step": round(bytes_alg), "achieved_GB_s": round(bytes_alg / (step_us * 1e-6) / 1e9, 1),
+                        "peak_GB_s": 8000.0, "frac": round(bytes_alg / (step_us * 1e-6) / 8e12, 4)},
+                "note": "the equivalent rate exceeds the FP64 peak because the exact staged bound scores most "
+                        "models on a fraction of the points; counters for this kernel: profiles/",
+            }
+        if configs2:
+            out["configs2"] = configs2
+        if allp:
+            out["allpairs"] = allp
         if not args.no_cpu_baseline and world == 1:  # the CPU leg belongs to the single-GPU line only
-            threads = int(os.environ.get("OMP_NUM_THREADS", "8"))
-            threads = max(1, min(threads, 64))
+            threads = host_threads()
             cb = cpu_baseline(descs, kps, nh, threads, min(B, 16))
             out["cpu_baseline"] = {
                 "value": round(cb["n_pairs"] / cb["seconds"], 4),
                 "unit": "pairs/s",
                 "cores": threads,
                 "kind": "port",
-                "sample": "%d full pairs of the batch (%dx%d kNN on %d threads + ratio + F-RANSAC %d hyps on 1 "
-                          "thread): %.2f s kNN, %.2f s RANSAC; inliers/pair %.1f (GPU: %.1f)" %
-                          (cb["n_pairs"], n, n, threads, nh, cb["knn_seconds"], cb["ransac_seconds"],
+                "host_cpus_visible": os.cpu_count(),
+                "sample": "%d full pairs of the batch (%dx%d kNN threaded over query rows + ratio + F-RANSAC %d hyps "
+                          "threaded over hypotheses, %d threads = this process's CPU share): %.2f s kNN, %.2f s "
+                          "RANSAC; inliers/pair %.1f (GPU: %.1f)" %
+                          (cb["n_pairs"], n, n, nh, threads, cb["knn_seconds"], cb["ransac_seconds"],
                            cb["n_inliers"], float(np.mean(n_inl[:cb["n_pairs"]]))),
             }
         print(json.dumps(out), flush=True)

@@ -219,6 +219,26 @@ def ransac(pts1, pts2, K=None, model=MODEL_ESSENTIAL, prob=0.99, threshold=1.0, 
                 counts=counts)
 
 
+def ransac_fixed_mt(pts1, pts2, K=None, model=MODEL_ESSENTIAL, threshold=1.0, fixed_count=2048, nthreads=8):
+    """Fixed-count RANSAC with the hypotheses spread over threads; same result as
+    ransac(..., fixed_count=...).  Returns dict(ok, mask, model, n_inliers)."""
+    pts1 = np.ascontiguousarray(pts1, dtype=np.float64).reshape(-1, 2)
+    pts2 = np.ascontiguousarray(pts2, dtype=np.float64).reshape(-1, 2)
+    n = pts1.shape[0]
+    Kc = np.ascontiguousarray(K if K is not None else np.eye(3), dtype=np.float64)
+    mask = np.zeros(n, dtype=np.uint8)
+    model_out = np.zeros((3, 3), dtype=np.float64)
+    n_inl = ctypes.c_int32(0)
+    L = lib()
+    L.oracle_ransac_fixed_mt.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p]
+    L.oracle_ransac_fixed_mt.restype = ctypes.c_int
+    ok = L.oracle_ransac_fixed_mt(model, _p(pts1), _p(pts2), n, _p(Kc), threshold, fixed_count, nthreads, _p(mask),
+                                  _p(model_out), ctypes.byref(n_inl))
+    return dict(ok=ok, mask=mask, model=model_out, n_inliers=n_inl.value)
+
+
 def ransac_direct_models():
     """Candidates of the calling thread's last n == m ransac() call, [k, 3, 3]."""
     out = np.zeros((10, 3, 3), dtype=np.float64)

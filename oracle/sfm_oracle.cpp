@@ -1046,6 +1046,90 @@ double oracle_normalize_points(const double* pts_px, int n, const double* K, dou
     return threshold_px / ((fx + fy) / 2);
 }
 
+// Fixed-count RANSAC with the hypotheses spread over threads (the timed CPU
+// baseline of the benchmark; the result is the sequential loop's: the first
+// hypothesis and model, in scan order, that reaches the largest inlier count).
+int oracle_ransac_fixed_mt(int model_kind, const double* pts1, const double* pts2, int n, const double* K,
+                           double threshold_px, int fixed_count, int nthreads, uint8_t* mask, double* model_out,
+                           int32_t* n_inliers)
+{
+    if ((model_kind != 0 && model_kind != 1) || n < 0 || fixed_count < 1) return -1;
+    const int m = model_kind == 0 ? 5 : 7;
+    if (n_inliers) *n_inliers = 0;
+    if (n <= m) return oracle_ransac(model_kind, pts1, pts2, n, K, 0.99, threshold_px, 1000, fixed_count, nullptr, mask,
+                                     model_out, n_inliers, nullptr, nullptr);
+    std::vector<double> x1, x2;
+    std::vector<float> f1, f2;
+    double thr = threshold_px;
+    if (model_kind == 0) {
+        x1.resize(2 * (size_t)n);
+        x2.resize(2 * (size_t)n);
+        thr = oracle_normalize_points(pts1, n, K, threshold_px, x1.data());
+        oracle_normalize_points(pts2, n, K, threshold_px, x2.data());
+    } else {
+        f1.resize(2 * (size_t)n);
+        f2.resize(2 * (size_t)n);
+        for (int i = 0; i < 2 * n; i++) { f1[i] = (float)pts1[i]; f2[i] = (float)pts2[i]; }
+    }
+    const float t = (float)(thr * thr);
+    if (nthreads < 1) nthreads = 1;
+    nthreads = std::min(nthreads, fixed_count);
+    struct Best { int good = 0; double model[9]; };
+    std::vector<Best> best(nthreads);
+    auto work = [&](int tid, int h0, int h1) {
+        std::vector<float> err(n);
+        Best& b = best[tid];
+        double models[10 * 9];
+        for (int iter = h0; iter < h1; iter++) {
+            int idx[7];
+            fixed_row(n, m, (uint32_t)iter, model_kind == 1 ? f1.data() : nullptr, model_kind == 1 ? f2.data() : nullptr,
+                      idx);
+            if (idx[0] < 0) continue;
+            int nm;
+            if (model_kind == 0) {
+                double a[10], c[10];
+                for (int i = 0; i < 5; i++) {
+                    a[2 * i] = x1[2 * idx[i]]; a[2 * i + 1] = x1[2 * idx[i] + 1];
+                    c[2 * i] = x2[2 * idx[i]]; c[2 * i + 1] = x2[2 * idx[i] + 1];
+                }
+                nm = five_point(a, c, models);
+            } else {
+                float a[14], c[14];
+                for (int i = 0; i < 7; i++) {
+                    a[2 * i] = f1[2 * idx[i]]; a[2 * i + 1] = f1[2 * idx[i] + 1];
+                    c[2 * i] = f2[2 * idx[i]]; c[2 * i + 1] = f2[2 * idx[i] + 1];
+                }
+                nm = seven_point(a, c, models);
+            }
+            for (int q = 0; q < nm; q++) {
+                if (model_kind == 0) sampson(models + 9 * q, x1.data(), x2.data(), n, err.data());
+                else symepi(models + 9 * q, f1.data(), f2.data(), n, err.data());
+                int good = 0;
+                for (int i = 0; i < n; i++) good += err[i] <= t;
+                if (good > std::max(b.good, m - 1)) {
+                    b.good = good;
+                    std::memcpy(b.model, models + 9 * q, sizeof(b.model));
+                }
+            }
+        }
+    };
+    const int per = (fixed_count + nthreads - 1) / nthreads;
+    std::vector<std::thread> th;
+    for (int k = 0; k < nthreads; k++) th.emplace_back(work, k, k * per, std::min(fixed_count, (k + 1) * per));
+    for (auto& x : th) x.join();
+    int win = -1, good = 0;
+    for (int k = 0; k < nthreads; k++)   // ascending hypothesis ranges, strict >: the sequential loop's choice
+        if (best[k].good > std::max(good, m - 1)) { good = best[k].good; win = k; }
+    if (win < 0) return 0;
+    std::memcpy(model_out, best[win].model, 9 * sizeof(double));
+    std::vector<float> err(n);
+    if (model_kind == 0) sampson(model_out, x1.data(), x2.data(), n, err.data());
+    else symepi(model_out, f1.data(), f2.data(), n, err.data());
+    for (int i = 0; i < n; i++) mask[i] = (uint8_t)(err[i] <= t);
+    if (n_inliers) *n_inliers = good;
+    return 1;
+}
+
 // candidates of the last direct (n == m) solve on this thread
 static thread_local int g_direct_n = 0;
 static thread_local double g_direct_models[10 * 9];

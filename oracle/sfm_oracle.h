@@ -131,6 +131,13 @@ int oracle_ransac(int model_kind, const double* pts1, const double* pts2, int n,
                   uint8_t* mask, double* model_out, int32_t* n_inliers,
                   int32_t* iters_used, int32_t* hyp_counts);
 
+/* oracle_ransac in fixed-count mode with the hypotheses spread over `nthreads`
+ * threads; same winner, mask, model and count as the sequential loop (own
+ * counter-based sample table only).  Used as the timed CPU baseline. */
+int oracle_ransac_fixed_mt(int model_kind, const double* pts1, const double* pts2, int n,
+                           const double* K, double threshold_px, int fixed_count, int nthreads,
+                           uint8_t* mask, double* model_out, int32_t* n_inliers);
+
 /* With n == m points cv::findEssentialMat / findFundamentalMat return every
  * candidate of the one direct solve stacked (3k x 3); oracle_ransac reports the
  * first in model_out, this returns all k of the calling thread's last such call

@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --pmc "$@" -d "$OUT/run" -o bench --output-format csv -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-microkernel > "$OUT/pmc.log" 2>&1 || { echo "pmc failed"; tail -5 "$OUT/pmc.log"; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc "$@" -d "$OUT/run" -o bench --output-format csv -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-microkernel --no-configs2 --no-allpairs > "$OUT/pmc.log" 2>&1 || { echo "pmc failed"; tail -5 "$OUT/pmc.log"; exit 1; }
 f=$(find "$OUT/run" -name '*counter_collection.csv' | head -1)
 cp "$f" "$OUT/counters.csv"
 python3 - "$OUT/counters.csv" "$PAT" <<'PY'

@@ -105,12 +105,13 @@ def deal_pairs(pairs, rows, world):
     return [np.array(sorted(o), np.int64) for o in out]
 
 
-def match_all_pairs(local_images, n_images, backend, mode="all", group=None, device=None):
+def match_all_pairs(local_images, n_images, backend, mode="all", group=None, device=None, return_stats=False):
     """Matches all pairs of `n_images` images spread over the ranks of `group`.
 
     local_images: this rank's images, in global order (owned_range()).
     Returns (pairs [P,2], n_good [V,V], n_inliers [V,V]) on every rank; the
-    matrices hold pair (i, j) at [i, j] and zeros elsewhere.
+    matrices hold pair (i, j) at [i, j] and zeros elsewhere.  return_stats adds a
+    dict with the bytes the all-gather delivered to this rank and its pair share.
     """
     import torch
     import torch.distributed as dist
@@ -134,23 +135,31 @@ def match_all_pairs(local_images, n_images, backend, mode="all", group=None, dev
     # 2. prepare where the images live
     blobs, rows = backend.prepare(local_images, max_rows)
     per_rank = (V + world - 1) // world  # owned_range gives at most this many
+    stats = {"world": world, "blob_bytes": int(blob_bytes), "gathered_bytes": 0}
     if distributed and world > 1:
-        # 3. one all-gather of equally sized slabs (short ranks pad with zeros)
-        slab = torch.zeros((per_rank, blob_bytes), dtype=torch.uint8, device=blobs.device)
-        slab_rows = torch.zeros(per_rank, dtype=torch.int32, device=blobs.device)
-        slab[: hi - lo] = blobs
-        slab_rows[: hi - lo] = rows
-        all_slabs = torch.empty((world * per_rank, blob_bytes), dtype=torch.uint8, device=blobs.device)
-        all_rows = torch.empty(world * per_rank, dtype=torch.int32, device=blobs.device)
+        # 3. one all-gather of equally sized slabs (short ranks pad with zeros).
+        # RCCL moves device memory; a gloo group (CPU rehearsal of the same control
+        # flow) is handed host copies.
+        on_host = dist.get_backend(group) == "gloo" and blobs.is_cuda
+        cdev = torch.device("cpu") if on_host else blobs.device
+        slab = torch.zeros((per_rank, blob_bytes), dtype=torch.uint8, device=cdev)
+        slab_rows = torch.zeros(per_rank, dtype=torch.int32, device=cdev)
+        slab[: hi - lo] = blobs.to(cdev)
+        slab_rows[: hi - lo] = rows.to(cdev)
+        all_slabs = torch.empty((world * per_rank, blob_bytes), dtype=torch.uint8, device=cdev)
+        all_rows = torch.empty(world * per_rank, dtype=torch.int32, device=cdev)
         dist.all_gather_into_tensor(all_slabs, slab, group=group)
         dist.all_gather_into_tensor(all_rows, slab_rows, group=group)
+        stats["gathered_bytes"] = int(all_slabs.numel() + all_rows.numel() * 4)
         index = []
         for r in range(world):
             rlo, rhi = owned_range(V, world, r)
             index += [r * per_rank + k for k in range(rhi - rlo)]
-        index = torch.tensor(index, dtype=torch.int64, device=blobs.device)
+        index = torch.tensor(index, dtype=torch.int64, device=cdev)
         all_blobs = all_slabs.index_select(0, index) if len(index) != world * per_rank else all_slabs
         all_rows = all_rows.index_select(0, index)
+        if on_host:
+            all_blobs = all_blobs.to(blobs.device)
     else:
         all_blobs, all_rows = blobs, rows
 
@@ -170,18 +179,36 @@ def match_all_pairs(local_images, n_images, backend, mode="all", group=None, dev
     # 5. one all-reduce of the result matrices
     if distributed and world > 1:
         both = torch.stack([good, inl])
+        if dist.get_backend(group) == "gloo" and both.is_cuda:
+            both = both.cpu()
         dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
         good, inl = both[0], both[1]
+    if return_stats:
+        stats["pairs_mine"] = int(len(mine))
+        return pairs, good.cpu().numpy(), inl.cpu().numpy(), stats
     return pairs, good.cpu().numpy(), inl.cpu().numpy()
 
 
 class GpuBackend:
     """libsfm_gpu.so on the current GPU.  An image is (descriptors [n,128]
-    float32/uint8 numpy array or CUDA tensor, keypoints [n,2] float32)."""
+    float32/uint8 numpy array or CUDA tensor, keypoints [n,2] float32, same).
+
+    The library launches on the context's stream; tensors handed to it (CUDA
+    descriptors, the zero-filled blocks, the all-gather's output) are produced on
+    torch's current stream.  When the two differ the backend makes torch's stream
+    wait before the library reads and the library's before torch reads; a context
+    created on torch's stream (Context(dev, stream=torch.cuda.current_stream()
+    .cuda_stream)) needs neither."""
 
     def __init__(self, ctx, **match_kwargs):
         self.ctx = ctx
         self.match_kwargs = match_kwargs
+
+    def _torch_to_library(self):
+        import torch
+        cur = torch.cuda.current_stream()
+        if self.ctx.stream is None or self.ctx.stream != cur.cuda_stream:
+            cur.synchronize()  # what torch queued is done before the library's stream touches it
 
     @staticmethod
     def rows_of(image):
@@ -199,26 +226,30 @@ class GpuBackend:
         dev = torch.device("cuda", torch.cuda.current_device())
         blobs = torch.zeros((len(images), blk), dtype=torch.uint8, device=dev)
         rows = torch.tensor([self.rows_of(im) for im in images], dtype=torch.int32, device=dev)
-        keep = []
+        keep = {}
         for k, (desc, kp) in enumerate(images):
             d = torch.as_tensor(np.ascontiguousarray(desc) if isinstance(desc, np.ndarray) else desc).to(dev)
             p = torch.as_tensor(np.ascontiguousarray(kp, dtype=np.float32) if isinstance(kp, np.ndarray)
                                 else kp).to(dev).contiguous()
             d = d.contiguous()
-            dtype = matcher.DESC_U8 if d.dtype == torch.uint8 else matcher.DESC_F32
-            if dtype == matcher.DESC_F32 and d.dtype != torch.float32:
+            if d.dtype not in (torch.uint8, torch.float32):
                 raise TypeError("descriptors must be float32 or uint8")
-            keep.append((d, p))
             if d.shape[0] > 0:
-                matcher.prepare_many(self.ctx, [d.data_ptr()], [d.shape[0]], d.stride(0) * d.element_size(),
-                                     dtype, [p.data_ptr()], [blobs[k].data_ptr()])
-        matcher.check_inputs(self.ctx)  # also waits, so `keep` may go
+                keep.setdefault(d.dtype, []).append((k, d, p))
+        self._torch_to_library()
+        for dt, items in keep.items():  # one launch per element type
+            matcher.prepare_many(self.ctx, [d.data_ptr() for _, d, _ in items], [d.shape[0] for _, d, _ in items],
+                                 128 * items[0][1].element_size(),
+                                 matcher.DESC_U8 if dt == torch.uint8 else matcher.DESC_F32,
+                                 [p.data_ptr() for _, _, p in items], [blobs[k].data_ptr() for k, _, _ in items])
+        matcher.check_inputs(self.ctx)  # waits for the conversion, so `keep` may go and torch may read
         return blobs, rows
 
     def match(self, blobs, rows, pairs):
         from . import matcher
         used = sorted(set(int(v) for v in np.asarray(pairs).reshape(-1)))
         remap = {g: k for k, g in enumerate(used)}
+        self._torch_to_library()  # the gathered blocks were written on torch's (or RCCL's) stream
         imgs = [matcher.WrappedImage(self.ctx, blobs[g].data_ptr(), int(rows[g])) for g in used]
         local_pairs = np.array([[remap[int(a)], remap[int(b)]] for a, b in pairs], np.int32)
         try:

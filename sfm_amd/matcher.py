@@ -35,6 +35,7 @@ class Context:
             raise SfmGpuError(rc, "sfm_gpu_create failed (no GPU, or bad device id %d)" % device_id)
         self.handle = h
         self.device_id = device_id
+        self.stream = stream  # hipStream_t the context launches on, None: a stream of its own
 
     def check(self, rc):
         if rc != 0:
