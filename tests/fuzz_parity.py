@@ -99,6 +99,15 @@ def trial_ransac(ctx, rng, idx, stats):
         what = "fixed nh=%d" % nh
     else:
         mi = int(rng.choice([1, 10, 100, 1000, 2000]))
+        if model == 1 and 7 < n < 15:
+            # cv::findFundamentalMat runs LMedS here: the library must refuse, not run RANSAC
+            try:
+                matcher._ransac(ctx, p1, p2, K, model, prob, thr, mi, matcher.RANSAC_ADAPTIVE, None, 0, None)
+            except matcher.SfmGpuError as e:
+                stats["refused"] = stats.get("refused", 0) + 1
+                return 0 if e.code == -5 else 1
+            print("MISMATCH ransac #%d: fundamental adaptive with n=%d was not refused" % (idx, n), flush=True)
+            return 1
         o = oracle.ransac(p1, p2, K, model=model, prob=prob, threshold=thr, max_iters=mi)
         r = matcher._ransac(ctx, p1, p2, K, model, prob, thr, mi, matcher.RANSAC_ADAPTIVE, None, 0, None)
         what = "adaptive max_iters=%d" % mi
@@ -271,17 +280,15 @@ def trial_tracks(ctx, rng, idx, stats):
     return 0
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seconds", type=float, default=120.0)
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--only", default="", help="comma list of ransac,knn,pairs,tracks")
-    args = ap.parse_args()
-    rng = np.random.default_rng(args.seed)
-    ctx = matcher.Context(0)
+def run(seconds, seed, only="", ctx=None, quiet=False):
+    """Draws trials for `seconds`; returns (fails, trials, stats)."""
+    rng = np.random.default_rng(seed)
+    own = ctx is None
+    if own:
+        ctx = matcher.Context(0)
     bf = matcher.BFMatcher(ctx)
     stats = dict(ransac=0, ransac_ok=0, model_last_bits=0, pose=0, knn=0, pairs=0, tracks=0)
-    only = [s for s in args.only.split(",") if s]
+    only = [s for s in only.split(",") if s]
     menu = [("ransac", 6), ("knn", 2), ("pairs", 1), ("tracks", 1)]
     menu = [(k, w) for k, w in menu if not only or k in only]
     names = [k for k, _ in menu]
@@ -291,7 +298,7 @@ def main():
     t0 = time.time()
     last = t0
     idx = 0
-    while time.time() - t0 < args.seconds:
+    while time.time() - t0 < seconds:
         what = names[int(rng.choice(len(names), p=weights))]
         if what == "ransac":
             fails += trial_ransac(ctx, rng, idx, stats)
@@ -302,11 +309,22 @@ def main():
         else:
             fails += trial_tracks(ctx, rng, idx, stats)
         idx += 1
-        if time.time() - last > 20:
+        if not quiet and time.time() - last > 20:
             last = time.time()
             print("[%4.0fs] trials=%d fails=%d %s" % (last - t0, idx, fails, stats), flush=True)
+    if own:
+        ctx.close()
+    return fails, idx, stats
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", default="", help="comma list of ransac,knn,pairs,tracks")
+    args = ap.parse_args()
+    fails, idx, stats = run(args.seconds, args.seed, args.only)
     print("done: trials=%d fails=%d %s" % (idx, fails, stats), flush=True)
-    ctx.close()
     sys.exit(1 if fails else 0)
 
 

@@ -1,0 +1,92 @@
+"""Full-size and randomised GPU parity: the benchmark's own configuration
+against the CPU oracle, a bounded slice of the randomised sweep, and the
+exhaustive matcher at 20 000 descriptors per view."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from sfm_amd import allpairs, matcher, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_pair(oracle, dq, dt, kq, kt, K, ratio, model, **kw):
+    m, c = oracle.knn_match(dq, dt, 2, nthreads=16)
+    keep = oracle.ratio_test(m, c, ratio)
+    good = m[keep, 0]
+    p1 = kq[good["queryIdx"]].astype(np.float64)
+    p2 = kt[good["trainIdx"]].astype(np.float64)
+    r = oracle.ransac(p1, p2, K, model=model, **kw)
+    sel = good[r["mask"].astype(bool)] if r["ok"] else good[:0]
+    return len(good), sel
+
+
+def test_bench_configuration_full_size_against_oracle(gpu_ctx, oracle):
+    """BASELINE configs[1] as bench.py runs it: pairs of 8192 x 8192 float32
+    descriptors, ratio 0.7, fundamental RANSAC with 2048 hypotheses (fixed count),
+    two pairs of the bench batch through sfm_gpu_match_pairs.  Survivor counts,
+    inlier counts and every selected cv::DMatch record (distance bits included)
+    must equal the oracle pipeline's."""
+    sys.path.insert(0, ROOT)
+    from bench import make_pairs
+    descs, kps = make_pairs(2, 8192, 1000, 0.07)
+    imgs = [matcher.Image(gpu_ctx, d, k) for d, k in zip(descs, kps)]
+    pairs = np.array([[0, 1], [2, 3]], np.int32)
+    ng, ni, sel = matcher.match_pairs(gpu_ctx, imgs, pairs, None, ratio=0.7, model=matcher.MODEL_FUNDAMENTAL,
+                                      mode=matcher.RANSAC_FIXED, prob=0.99, threshold=3.0, n_hyp=2048,
+                                      want_matches=True)
+    for p in range(2):
+        og, osel = _oracle_pair(oracle, descs[2 * p], descs[2 * p + 1], kps[2 * p], kps[2 * p + 1], None, 0.7,
+                                oracle.MODEL_FUNDAMENTAL, prob=0.99, threshold=3.0, fixed_count=2048)
+        assert ng[p] == og and ni[p] == len(osel)
+        assert sel[p].tobytes() == osel.astype(matcher.DMATCH_DTYPE).tobytes()
+        assert 3000 < og < 3600 and len(osel) > 0.85 * og      # the planted structure is there
+    for im in imgs:
+        im.close()
+
+
+def test_randomised_parity_slice(gpu_ctx):
+    """25 seconds of tests/fuzz_parity.py (RANSAC in both models and modes on
+    degenerate scenes, recoverPose, ragged kNN, the pair pipeline, the track
+    join) with a fixed seed; no trial may differ from the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fuzz_parity
+    fails, trials, stats = fuzz_parity.run(25.0, 20261111, ctx=gpu_ctx, quiet=True)
+    assert fails == 0, stats
+    assert trials > 200 and stats["ransac"] > 50 and stats["knn"] > 10 and stats["pairs"] > 5, stats
+
+
+@pytest.mark.parametrize("own_stream", [True, False])
+def test_exhaustive_matcher_20000_descriptors_cuda_inputs(gpu_ctx, oracle, own_stream):
+    """sfm_amd.allpairs with the GPU backend on 6 views x 20 000 descriptors (the
+    per-view size of BASELINE configs[3]) whose descriptors are CUDA tensors
+    produced by asynchronous torch work right before the call, once with the
+    library on a stream of its own and once on torch's stream.  Three of the 15
+    pairs are checked against the oracle pipeline."""
+    import torch
+    V, n = 6, 20000
+    descs, kps, _ = synth.image_sequence(V, n, 4242, shared=0.4)
+    st = torch.cuda.Stream()
+    ctx = matcher.Context(0) if own_stream else matcher.Context(0, stream=st.cuda_stream)
+    be = allpairs.GpuBackend(ctx, K=synth.REF_K, model=matcher.MODEL_ESSENTIAL, mode=matcher.RANSAC_ADAPTIVE,
+                             prob=0.99, threshold=1.0, max_iters=1000)
+    with torch.cuda.stream(st):
+        junk = torch.randn(4096, 4096, device="cuda")
+        for _ in range(8):
+            junk = junk @ junk * 1e-3          # keeps torch's stream busy ahead of the uploads' consumers
+        local = []
+        for d, k in zip(descs, kps):
+            # values arrive through arithmetic on the stream, not through a synchronous copy
+            dd = torch.from_numpy(d).cuda(non_blocking=True)
+            local.append(((dd * 2.0 - dd).contiguous(), (torch.from_numpy(k).cuda(non_blocking=True) + 0.0)))
+        pairs, good, inl = allpairs.match_all_pairs(local, V, be, mode="all", device=torch.device("cuda", 0))
+    assert len(pairs) == 15
+    for (i, j) in ((0, 1), (2, 5), (3, 4)):
+        og, osel = _oracle_pair(oracle, descs[i], descs[j], kps[i], kps[j], synth.REF_K, 0.7,
+                                oracle.MODEL_ESSENTIAL, prob=0.99, threshold=1.0, max_iters=1000)
+        assert good[i, j] == og and inl[i, j] == len(osel), (i, j, good[i, j], og, inl[i, j], len(osel))
+    assert inl[0, 1] > 1000 and good[j, i] == 0
+    ctx.close()
