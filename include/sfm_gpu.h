@@ -185,6 +185,38 @@ int sfm_gpu_recover_pose(sfm_gpu_ctx* ctx, const double* E, const double* pts1,
                          const double* pts2, int n, const double* K, double distance_thresh,
                          double* R_out, double* t_out, uint8_t* mask, int32_t* n_good);
 
+/* ---- resection: replaces bundle_adjustment.h:139-155 -------------------- */
+
+/*
+ * solvePnPRansac(points_3d, pts, cameraMatrix, distortion_coeffs, r, t, false,
+ *                SOLVEPNP_EPNP)                         bundle_adjustment.h:154
+ * (Resection(), called per new image at main.cpp:520; distortion_coeffs is all
+ * zeros there, and this entry point takes none): RANSAC over five-point EPnP
+ * hypotheses drawn like OpenCV draws them (cv::RNG(-1), getSubset), inliers by
+ * squared reprojection distance <= reprojection_error^2 evaluated in float32,
+ * the self-shortening iteration count of RANSACUpdateNumIters, then one EPnP
+ * over all inliers.
+ *
+ *   object_pts    host, n x 3 doubles (vector<Point3d>)
+ *   image_pts     host, n x 2 doubles, pixels (vector<Point2d>)
+ *   K             host, 3x3 row-major camera matrix
+ *   iterations_count, reprojection_error, confidence
+ *                 OpenCV's defaults, which the reference takes: 100, 8.0, 0.99
+ *   rvec_out      out, 3 doubles: rotation vector (axis * angle), the `r` the
+ *                 reference feeds to Rodrigues() at main.cpp:522
+ *   tvec_out      out, 3 doubles
+ *   R_out         out, optional, 9 doubles row-major: the rotation matrix itself
+ *   inlier_mask   out, optional, n bytes 0/1 (OpenCV returns the inlier indices)
+ *   n_inliers, iters_used   out, optional
+ *   ok            out: 1 = a pose was found (solvePnPRansac's return value)
+ * n < 4: SFM_GPU_ERR_ARG (OpenCV asserts); n == 4: SFM_GPU_ERR_UNSUPPORTED
+ * (OpenCV switches to P3P); n == 5: one direct solve, every point an inlier.
+ */
+int sfm_gpu_pnp_ransac(sfm_gpu_ctx* ctx, const double* object_pts, const double* image_pts, int n,
+                       const double* K, int iterations_count, double reprojection_error,
+                       double confidence, double* rvec_out, double* tvec_out, double* R_out,
+                       uint8_t* inlier_mask, int32_t* n_inliers, int32_t* iters_used, int32_t* ok);
+
 /* ---- three-view track join: replaces main.cpp:442-456 ----------------- */
 
 /* Keypoint indices of one track in images i, i+1 and j. */
@@ -365,7 +397,8 @@ int sfm_gpu_stream_wait_front(sfm_gpu_ctx* waiter, sfm_gpu_ctx* source);
  * query returns accumulated milliseconds and launch count since the last
  * reset.  Kernel names: "knn2_mfma", "prep_rows", "knn_finalize",
  * "ratio_compact", "ransac_table", "ransac_solve", "ransac_score",
- * "ransac_select", "pose_vote", "track_join".  Has no counterpart in the reference.
+ * "ransac_select", "pose_vote", "track_join", "pnp_prep", "pnp_solve",
+ * "pnp_score".  Has no counterpart in the reference.
  */
 int sfm_gpu_profile_enable(sfm_gpu_ctx* ctx, int on);
 /* Restricts the timing to one named kernel (NULL: all of them), so that a

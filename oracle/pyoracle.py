@@ -249,6 +249,48 @@ def ransac_direct_models():
     return out[:max(k, 0)].copy()
 
 
+def epnp(object_pts, image_pts, K):
+    """EPnP pose: dict(ok, R, t)."""
+    X = np.ascontiguousarray(object_pts, dtype=np.float64).reshape(-1, 3)
+    u = np.ascontiguousarray(image_pts, dtype=np.float64).reshape(-1, 2)
+    Kc = np.ascontiguousarray(K, dtype=np.float64)
+    R = np.zeros((3, 3)); t = np.zeros(3)
+    L = lib()
+    L.oracle_epnp.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                              ctypes.c_void_p]
+    L.oracle_epnp.restype = ctypes.c_int
+    ok = L.oracle_epnp(_p(X), _p(u), X.shape[0], _p(Kc), _p(R), _p(t))
+    return dict(ok=ok, R=R, t=t)
+
+
+def rotation_vector(R):
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    r = np.zeros(3)
+    L = lib()
+    L.oracle_rotation_vector.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.oracle_rotation_vector(_p(R), _p(r))
+    return r
+
+
+def pnp_ransac(object_pts, image_pts, K, iterations_count=100, reprojection_error=8.0, confidence=0.99):
+    """cv::solvePnPRansac(..., SOLVEPNP_EPNP) restated: dict(ok, rvec, tvec, R, mask, n_inliers, iters)."""
+    X = np.ascontiguousarray(object_pts, dtype=np.float64).reshape(-1, 3)
+    u = np.ascontiguousarray(image_pts, dtype=np.float64).reshape(-1, 2)
+    n = X.shape[0]
+    Kc = np.ascontiguousarray(K, dtype=np.float64)
+    rvec = np.zeros(3); tvec = np.zeros(3); R = np.zeros((3, 3))
+    mask = np.zeros(n, np.uint8)
+    ni = ctypes.c_int32(0); it = ctypes.c_int32(0)
+    L = lib()
+    L.oracle_pnp_ransac.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.oracle_pnp_ransac.restype = ctypes.c_int
+    ok = L.oracle_pnp_ransac(_p(X), _p(u), n, _p(Kc), iterations_count, reprojection_error, confidence, _p(rvec),
+                             _p(tvec), _p(R), _p(mask), ctypes.byref(ni), ctypes.byref(it))
+    return dict(ok=ok, rvec=rvec, tvec=tvec, R=R, mask=mask, n_inliers=ni.value, iters=it.value)
+
+
 def svd3(A):
     A = np.ascontiguousarray(A, dtype=np.float64)
     U = np.zeros((3, 3)); S = np.zeros(3); V = np.zeros((3, 3))

@@ -144,6 +144,26 @@ int oracle_ransac_fixed_mt(int model_kind, const double* pts1, const double* pts
  * (capacity in models; -1 when it is too small). */
 int oracle_ransac_direct_models(double* models_out, int capacity);
 
+/* ---- resection: cv::solvePnPRansac(points_3d, pts, K, zeros, r, t, false,
+ * SOLVEPNP_EPNP), /root/reference/bundle_adjustment.h:139-155 (pnp_oracle.cpp) ---- */
+
+/* EPnP pose of n >= 4 correspondences (object points n x 3, pixel coordinates
+ * n x 2, all double): x_cam = R x_world + t.  1 ok, 0 degenerate, -1 bad n. */
+int oracle_epnp(const double* object_pts, const double* image_pts, int n, const double* K,
+                double* R, double* t);
+
+/* Rotation vector (axis * angle) of a rotation matrix. */
+int oracle_rotation_vector(const double* R, double* rvec);
+
+/* The whole call.  iterations_count 100, reprojection_error 8.0, confidence 0.99
+ * are OpenCV's defaults, which the reference takes.  mask: n bytes (0/1), left
+ * untouched on failure.  Returns 1 ok, 0 no pose, -1 bad arguments (n < 5: four
+ * points go to P3P in OpenCV, which is not restated). */
+int oracle_pnp_ransac(const double* object_pts, const double* image_pts, int n, const double* K,
+                      int iterations_count, double reprojection_error, double confidence,
+                      double* rvec, double* tvec, double* R_out, uint8_t* mask,
+                      int32_t* n_inliers, int32_t* iters_used);
+
 /* 3x3 singular value decomposition A = U diag(S) V^T by one-sided Jacobi
  * rotations (row-major, |S| descending, U[:,2] = U[:,0] x U[:,1] with S[2]
  * carrying the sign).  Returns 1, or 0 when A has rank < 2. */

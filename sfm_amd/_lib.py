@@ -85,6 +85,8 @@ def _load(path):
     L.sfm_gpu_ransac.argtypes = [vp, vp, vp, c.c_int, vp, c.c_int, c.c_double, c.c_double,
                                  c.c_int, c.c_int, vp, c.c_int, vp, vp, vp, vp, vp]
     L.sfm_gpu_ransac_candidates.argtypes = [vp, vp, c.c_int, vp]
+    L.sfm_gpu_pnp_ransac.argtypes = [vp, vp, vp, c.c_int, vp, c.c_int, c.c_double, c.c_double, vp, vp, vp, vp, vp,
+                                     vp, vp]
     L.sfm_gpu_image_create.argtypes = [vp, vp, c.c_int, c.c_size_t, c.c_int, c.c_int, vp, c.c_int,
                                        c.POINTER(vp)]
     L.sfm_gpu_image_destroy.argtypes = [vp, vp]

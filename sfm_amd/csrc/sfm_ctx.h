@@ -139,6 +139,8 @@ struct sfm_gpu_ctx {
     sfm::DevBuf mp_good, mp_pts, mp_ngood;
     // recover_pose workspaces
     sfm::DevBuf pose_in, pose_out;
+    // pnp_ransac workspace
+    sfm::DevBuf pnp_ws;
     int32_t dbg_pose_votes[4] = {0, 0, 0, 0};
     // Small host-to-device uploads (job descriptors) go through pinned staging
     // when a stage is set: a copy from pageable memory makes the host wait for

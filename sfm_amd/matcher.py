@@ -216,6 +216,30 @@ def recoverPose(ctx, E, points1, points2, cameraMatrix, distanceThresh=50.0, mas
     return good.value, R, t, m
 
 
+def solvePnPRansac(ctx, objectPoints, imagePoints, cameraMatrix, iterationsCount=100, reprojectionError=8.0,
+                   confidence=0.99):
+    """cv::solvePnPRansac(objectPoints, imagePoints, cameraMatrix, zeros, rvec, tvec,
+    false, iterationsCount, reprojectionError, confidence, inliers, SOLVEPNP_EPNP) as
+    Resection() calls it (bundle_adjustment.h:154).  Returns (ok, rvec, tvec, inliers,
+    info) with inliers = indices of the inlier points like OpenCV's output array and
+    info = dict(R, mask, n_inliers, iters)."""
+    X = np.ascontiguousarray(objectPoints, dtype=np.float64).reshape(-1, 3)
+    u = np.ascontiguousarray(imagePoints, dtype=np.float64).reshape(-1, 2)
+    if X.shape[0] != u.shape[0]:
+        raise ValueError("object and image points differ in length")
+    n = X.shape[0]
+    Kc = np.ascontiguousarray(cameraMatrix, dtype=np.float64).reshape(3, 3)
+    rvec = np.zeros(3); tvec = np.zeros(3); R = np.zeros((3, 3))
+    mask = np.zeros(max(n, 1), np.uint8)
+    ni = ctypes.c_int32(0); it = ctypes.c_int32(0); ok = ctypes.c_int32(0)
+    ctx.check(ctx._L.sfm_gpu_pnp_ransac(ctx.handle, ptr(X), ptr(u), n, ptr(Kc), int(iterationsCount),
+                                        float(reprojectionError), float(confidence), ptr(rvec), ptr(tvec), ptr(R),
+                                        ptr(mask), ctypes.byref(ni), ctypes.byref(it), ctypes.byref(ok)))
+    mask = mask[:n]
+    return bool(ok.value), rvec, tvec, np.flatnonzero(mask).astype(np.int32), dict(
+        R=R, mask=mask, n_inliers=ni.value, iters=it.value)
+
+
 def track_join(ctx, matches_ab, matches_bc, capacity=None):
     """The three-view join of main.cpp:442-456: [n, 3] int32 keypoint indices
     (image i, image i+1, image j), in the reference's loop order.  matches_bc

@@ -87,8 +87,30 @@ def tracks_case():
                         bc_query=bc["queryIdx"], bc_train=bc["trainIdx"], tracks=t)
 
 
+def pnp_case():
+    """Resection (bundle_adjustment.h:139-155): 600 object points seen by a planted
+    camera, 25 % of the pixels replaced by random ones, oracle_pnp_ransac defaults."""
+    rng = np.random.default_rng(41)
+    K = synth.REF_K
+    R = synth._rot(rng.normal(size=3), np.deg2rad(17.0))
+    t = np.array([12.0, -20.0, 640.0])
+    X = rng.uniform(-150, 150, (600, 3))
+    Xc = X @ R.T + t
+    u = Xc @ K.T
+    u = u[:, :2] / u[:, 2:] + rng.normal(0, 0.6, (600, 2))
+    u[:150] = rng.uniform(0, 1500, (150, 2))
+    perm = rng.permutation(600)
+    X, u = X[perm], u[perm]
+    o = po.pnp_ransac(X, u, K)
+    assert o["ok"] == 1
+    np.savez_compressed(os.path.join(HERE, "pnp_ransac.npz"), X=X, u=u, R=o["R"], rvec=o["rvec"], tvec=o["tvec"],
+                        mask=o["mask"], iters=o["iters"], n_inliers=o["n_inliers"], R_true=R, t_true=t)
+
+
 def main():
-    which = sys.argv[1:] or ["knn", "essential", "fundamental", "pose", "tracks"]
+    which = sys.argv[1:] or ["knn", "essential", "fundamental", "pose", "tracks", "pnp"]
+    if "pnp" in which:
+        pnp_case()
     if "knn" in which:
         knn_case()
     if "essential" in which:

@@ -65,6 +65,17 @@ def _track_lists(g, dtype):
     return ab, bc
 
 
+def test_oracle_reproduces_pnp_golden(oracle):
+    from sfm_amd import synth
+    g = load("pnp_ransac.npz")
+    o = oracle.pnp_ransac(g["X"], g["u"], synth.REF_K)
+    assert o["ok"] == 1 and o["iters"] == int(g["iters"]) and o["n_inliers"] == int(g["n_inliers"])
+    assert (o["mask"] == g["mask"]).all()
+    assert o["R"].tobytes() == g["R"].tobytes() and o["tvec"].tobytes() == g["tvec"].tobytes()
+    assert o["rvec"].tobytes() == g["rvec"].tobytes()
+    assert np.abs(o["R"] - g["R_true"]).max() < 2e-3 and np.abs(o["tvec"] - g["t_true"]).max() < 1.0
+
+
 def test_oracle_reproduces_track_golden(oracle):
     g = load("track_join.npz")
     ab, bc = _track_lists(g, oracle.DMATCH_DTYPE)

@@ -7,6 +7,7 @@ RANSAC iteration-count formula and the algebraic properties of an essential
 matrix.
 """
 import numpy as np
+import pytest
 
 from sfm_amd import synth
 
@@ -359,3 +360,64 @@ def test_track_join_is_the_nested_loop(oracle):
     want = [[int(x["queryIdx"]), int(x["trainIdx"]), int(y["trainIdx"])] for x in a for y in b
             if x["trainIdx"] == y["queryIdx"]]
     assert oracle.track_join(a, b).tolist() == want
+
+
+# ---- resection: EPnP + its RANSAC loop (bundle_adjustment.h:139-155) ----------------
+
+def _pnp_scene(n, noise, out_frac, seed):
+    from sfm_amd import synth
+    rng = np.random.default_rng(seed)
+    K = synth.REF_K
+    R = synth._rot(rng.normal(size=3), np.deg2rad(rng.uniform(5, 40)))
+    t = np.array([rng.normal() * 30, rng.normal() * 30, 600 + rng.normal() * 50])
+    X = rng.uniform(-150, 150, (n, 3))
+    Xc = X @ R.T + t
+    u = Xc @ K.T
+    u = u[:, :2] / u[:, 2:] + rng.normal(0, noise, (n, 2))
+    no = int(n * out_frac)
+    u[:no] = rng.uniform(0, 1500, (no, 2))
+    return K, X, u, R, t
+
+
+@pytest.mark.parametrize("n", [5, 6, 10, 100, 2000])
+def test_epnp_recovers_a_planted_pose_exactly_on_noise_free_points(oracle, n):
+    K, X, u, R, t = _pnp_scene(n, 0.0, 0.0, 100 + n)
+    r = oracle.epnp(X, u, K)
+    assert r["ok"] == 1
+    assert np.abs(r["R"] - R).max() < 1e-9 and np.abs(r["t"] - t).max() < 1e-6
+    assert abs(np.linalg.det(r["R"]) - 1.0) < 1e-12 and np.abs(r["R"] @ r["R"].T - np.eye(3)).max() < 1e-12
+
+
+def test_pnp_ransac_loop_semantics(oracle):
+    K, X, u, R, t = _pnp_scene(2000, 0.5, 0.3, 7)
+    o = oracle.pnp_ransac(X, u, K)
+    assert o["ok"] == 1 and 1350 <= o["n_inliers"] <= 1400 and (o["mask"][:600] == 0).mean() > 0.99
+    assert np.abs(o["R"] - R).max() < 1e-3 and np.abs(o["tvec"] - t).max() < 1.0
+    # the iteration count follows RANSACUpdateNumIters: 30 % outliers, 5-point samples,
+    # confidence 0.99 -> ln(0.01) / ln(1 - 0.7^5) = 25
+    assert o["iters"] == oracle.update_num_iters(0.99, 1 - o["n_inliers"] / 2000.0, 5, 100) == 25
+    # every reported inlier reprojects within the threshold, evaluated like the loop does (float32)
+    Xf = X.astype(np.float32).astype(np.float64)
+    p = Xf @ o["R"].T + o["tvec"]
+    # (the mask belongs to the winning hypothesis, the pose is the refit over its inliers: close, not equal)
+    pu = (p[:, :2] / p[:, 2:]) * [K[0, 0], K[1, 1]] + [K[0, 2], K[1, 2]]
+    d2 = ((pu - u) ** 2).sum(1)
+    assert (d2[o["mask"] == 1] < 64.0 * 1.5).all() and (d2[o["mask"] == 0] > 64.0 / 1.5).all()
+    # rotation vector: Rodrigues' formula gives the matrix back
+    th = np.linalg.norm(o["rvec"])
+    k = o["rvec"] / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    assert np.abs(np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx - o["R"]).max() < 1e-12
+    # a single iteration, and too few points
+    one = oracle.pnp_ransac(X, u, K, iterations_count=1)
+    assert one["iters"] <= 1
+    assert oracle.pnp_ransac(X[:4], u[:4], K)["ok"] == -1
+
+
+def test_rotation_vector_special_angles(oracle):
+    assert np.abs(oracle.rotation_vector(np.eye(3))).max() == 0.0
+    Rpi = np.diag([1.0, -1.0, -1.0])                       # half turn about x
+    assert np.allclose(oracle.rotation_vector(Rpi), [np.pi, 0, 0])
+    a = 0.3
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    assert np.allclose(oracle.rotation_vector(Rz), [0, 0, a])
