@@ -780,6 +780,20 @@ __device__ __forceinline__ void insert3(u64& a1, u64& a2, u64& a3, u64 v)
     }
 }
 
+// The three smallest of two ascending triples (a1<=a2<=a3, b1<=b2<=b3): the k-th
+// smallest of the union is the minimum over i+j=k of max(a_i, b_j).
+__device__ __forceinline__ void merge3(u64& a1, u64& a2, u64& a3, u64 b1, u64 b2, u64 b3)
+{
+    auto mn = [](u64 x, u64 y) { return x < y ? x : y; };
+    auto mx = [](u64 x, u64 y) { return x < y ? y : x; };
+    const u64 r1 = mn(a1, b1);
+    const u64 r2 = mn(mn(a2, b2), mx(a1, b1));
+    const u64 r3 = mn(mn(a3, b3), mn(mx(a2, b1), mx(a1, b2)));
+    a1 = r1;
+    a2 = r2;
+    a3 = r3;
+}
+
 // Exact neighbours from the sweep records.  32 lanes per query:
 //  1. the query's records (one per part and sweep lane) are reduced to the two best groups
 //     by (minimum x, tile, half) and to the smallest x of all the other groups;
@@ -827,23 +841,23 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
             auto key_of = [&](uint32_t p, uint32_t t0, uint32_t sub) -> u64 {
                 return ((u64)(p >> TILE_BITS) << 32) | (((t0 + (p & tmask)) << SB) | sub);
             };
-            // one record per (part, lane of the query in the sweep)
+            // One record per (part, lane of the query in the sweep), its three groups
+            // already in ascending order.  A lane's third group may be the second
+            // best of all, so all three keep their identity.
             for (int j = part; j < n_splits * SUBS; j += 8) {
                 const int sp = j / SUBS;
                 const uint32_t sub = (uint32_t)(j - sp * SUBS);
                 const uint4 r = job.partial[((size_t)sp * job.q_rows_alloc + q) * REC_SUBS + sub];
                 const uint32_t t0 = r.w;
-                if (r.x != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.x, t0, sub));
-                if (r.y != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.y, t0, sub));
-                // a lane's third group may be the second best of all: it keeps its identity
-                if (r.z != 0xFFFFFFFFu) insert3(c1, c2, c3, key_of(r.z, t0, sub));
+                const u64 b1 = r.x != 0xFFFFFFFFu ? key_of(r.x, t0, sub) : NONE;
+                const u64 b2 = r.y != 0xFFFFFFFFu ? key_of(r.y, t0, sub) : NONE;
+                const u64 b3 = r.z != 0xFFFFFFFFu ? key_of(r.z, t0, sub) : NONE;
+                merge3(c1, c2, c3, b1, b2, b3);
             }
         }
         for (int off = 1; off < 8 && off < n_splits * SUBS; off <<= 1) {
             const u64 b1 = __shfl_xor(c1, off), b2 = __shfl_xor(c2, off), b3 = __shfl_xor(c3, off);
-            insert3(c1, c2, c3, b1);
-            insert3(c1, c2, c3, b2);
-            insert3(c1, c2, c3, b3);
+            merge3(c1, c2, c3, b1, b2, b3);
         }
         if (part == 0 && q < job.n_query) {
             need = true;
