@@ -245,6 +245,28 @@ int sfm_gpu_track_join(sfm_gpu_ctx* ctx, const sfm_gpu_dmatch* matches_ab, int n
                        const sfm_gpu_dmatch* matches_bc, int n_bc, sfm_gpu_track3* tracks,
                        int capacity, int32_t* n_tracks);
 
+/*
+ * The loop of main.cpp:432-456 around that join, for a whole sequence at once:
+ * list l (the selectMatches of pair l, as sfm_gpu_match_pairs returns them:
+ * n_matches[l] records at matches + l * match_capacity) is joined with list
+ * l + 1 for l = 0 .. n_lists - 2, in one upload, three launches and one
+ * download instead of a call per image.
+ *
+ *   tracks, track_capacity   out, room for `track_capacity` triples in all
+ *   track_offsets            out, n_lists int32: join l's triples are
+ *                            tracks[track_offsets[l] .. track_offsets[l+1]), in the
+ *                            order sfm_gpu_track_join gives; the last entry is
+ *                            their total.  When that exceeds track_capacity the
+ *                            call returns SFM_GPU_ERR_CAPACITY with the offsets
+ *                            set (the total tells how much room a second call
+ *                            needs) and writes no triples.
+ * Every list but the first must be in ascending queryIdx order
+ * (SFM_GPU_ERR_UNSUPPORTED otherwise).
+ */
+int sfm_gpu_track_join_sequence(sfm_gpu_ctx* ctx, const sfm_gpu_dmatch* matches, const int32_t* n_matches,
+                                int match_capacity, int n_lists, sfm_gpu_track3* tracks,
+                                int track_capacity, int32_t* track_offsets);
+
 /* ---- device-resident images: the all-pairs driver --------------------- */
 
 /*
@@ -351,6 +373,25 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
                         int n_pairs, const sfm_gpu_match_params* params, int32_t* n_good,
                         int32_t* n_inliers, sfm_gpu_dmatch* inlier_matches,
                         int match_capacity);
+
+/*
+ * sfm_gpu_match_pairs followed, for every pair, by what main.cpp:400-420 does
+ * with the first pair: recoverPose(E, pointsL, pointsR, K, R, T) on the pair's
+ * selectMatches -- here with the essential matrix the pair's own RANSAC found
+ * (params->model must be SFM_GPU_MODEL_ESSENTIAL) and without the points ever
+ * leaving the GPU: one vote launch per group of pairs.
+ *
+ *   distance_thresh   as in sfm_gpu_recover_pose (OpenCV's default: 50.0)
+ *   models_out    out, optional: n_pairs x 9 doubles, each pair's essential matrix
+ *   R_out, t_out  out: n_pairs x 9 and n_pairs x 3 doubles
+ *   n_pose_good   out, per pair: recoverPose's return value; -1 (and R, t, model
+ *                 all zero) for a pair whose RANSAC found no model
+ */
+int sfm_gpu_match_pairs_pose(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images,
+                             const int32_t* pairs, int n_pairs, const sfm_gpu_match_params* params,
+                             int32_t* n_good, int32_t* n_inliers, sfm_gpu_dmatch* inlier_matches,
+                             int match_capacity, double distance_thresh, double* models_out,
+                             double* R_out, double* t_out, int32_t* n_pose_good);
 
 /*
  * The same work split into "enqueue" and "collect", so that a host can put the

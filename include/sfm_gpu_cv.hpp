@@ -9,12 +9,14 @@
 //                                                     main.cpp:224, :418; bundle_adjustment.h:79
 //   recoverPose       recoverPose(E, p1, p2, K, R, T)       main.cpp:420; bundle_adjustment.h:80
 //   trackJoin         the nested loop over two match lists              main.cpp:442-456
+//   trackJoinSequence that loop for every image of the sequence         main.cpp:432-456
 //   solvePnPRansac    solvePnPRansac(pts3d, pts, K, dist, r, t, false, SOLVEPNP_EPNP)
 //                                                              bundle_adjustment.h:139-155
 // Errors of the C ABI surface as cv::Exception, like the calls they replace.
 #ifndef SFM_GPU_CV_HPP
 #define SFM_GPU_CV_HPP
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -117,6 +119,35 @@ public:
         check(rc);
         t.resize(n);
         return t;
+    }
+
+    // The loop of main.cpp:432-456 for a whole sequence: matches[l] against matches[l+1] for every l,
+    // in one call.  tracks[l] are the triples of images (l, l+1, j).
+    std::vector<std::vector<sfm_gpu_track3>> trackJoinSequence(const std::vector<std::vector<cv::DMatch>>& matches) const
+    {
+        const int n_lists = (int)matches.size();
+        std::vector<std::vector<sfm_gpu_track3>> tracks(n_lists > 1 ? n_lists - 1 : 0);
+        if (n_lists < 2) return tracks;
+        size_t cap = 1, room = 1;
+        for (const auto& m : matches) cap = std::max(cap, m.size());
+        for (int l = 0; l + 1 < n_lists; ++l) room += matches[l].size();
+        std::vector<sfm_gpu_dmatch> packed(cap * n_lists);
+        std::vector<int32_t> sizes(n_lists), offs(n_lists, 0);
+        for (int l = 0; l < n_lists; ++l) {
+            sizes[l] = (int32_t)matches[l].size();
+            if (sizes[l]) std::memcpy(&packed[cap * l], matches[l].data(), sizeof(sfm_gpu_dmatch) * matches[l].size());
+        }
+        std::vector<sfm_gpu_track3> flat(room);
+        int rc = sfm_gpu_track_join_sequence(ctx_, packed.data(), sizes.data(), (int)cap, n_lists, flat.data(),
+                                             (int)flat.size(), offs.data());
+        if (rc == SFM_GPU_ERR_CAPACITY) {  // repeated query rows: more triples than matches
+            flat.resize(offs[n_lists - 1]);
+            rc = sfm_gpu_track_join_sequence(ctx_, packed.data(), sizes.data(), (int)cap, n_lists, flat.data(),
+                                             (int)flat.size(), offs.data());
+        }
+        check(rc);
+        for (int l = 0; l + 1 < n_lists; ++l) tracks[l].assign(flat.begin() + offs[l], flat.begin() + offs[l + 1]);
+        return tracks;
     }
 
     // bundle_adjustment.h:154 (distortion coefficients are all zero there and are not taken)

@@ -103,6 +103,8 @@ def _load(path):
     L.sfm_gpu_knn_match_images_noalloc.argtypes = [vp, vp, vp, c.c_int, vp, vp]
     L.sfm_gpu_match_pairs.argtypes = [vp, vp, c.c_int, vp, c.c_int, c.POINTER(MatchParams), vp, vp, vp,
                                       c.c_int]
+    L.sfm_gpu_match_pairs_pose.argtypes = [vp, vp, c.c_int, vp, c.c_int, c.POINTER(MatchParams), vp, vp, vp,
+                                           c.c_int, c.c_double, vp, vp, vp, vp]
     L.sfm_gpu_match_pairs_begin.argtypes = [vp, vp, c.c_int, vp, c.c_int, c.POINTER(MatchParams)]
     L.sfm_gpu_match_pairs_end.argtypes = [vp, vp, vp, c.c_int]
     L.sfm_gpu_stream_wait_front.argtypes = [vp, vp]
@@ -124,6 +126,7 @@ def _load(path):
     L.sfm_gpu_debug_pose_votes.argtypes = [vp, vp]
     L.sfm_gpu_debug_set_score_prune.argtypes = [vp, c.c_int]
     L.sfm_gpu_track_join.argtypes = [vp, vp, c.c_int, vp, c.c_int, vp, c.c_int, vp]
+    L.sfm_gpu_track_join_sequence.argtypes = [vp, vp, vp, c.c_int, c.c_int, vp, c.c_int, vp]
     L.sfm_gpu_recover_pose.argtypes = [vp, vp, vp, vp, c.c_int, vp, c.c_double, vp, vp, vp, vp]
     return L
 

@@ -9,6 +9,9 @@
 #include <cmath>
 #include <cstring>
 
+#include <vector>
+
+#include "ransac_dev.h"
 #include "sfm_ctx.h"
 #include "sfm_gpu_debug.h"
 
@@ -79,6 +82,52 @@ __global__ __launch_bounds__(256) void pose_vote_kernel(const double2* __restric
     }
     __syncthreads();
     if (threadIdx.x < 4 && s_votes[threadIdx.x]) atomicAdd(&votes[threadIdx.x], s_votes[threadIdx.x]);
+}
+
+// The same vote for every pair of a sfm_gpu_match_pairs group at once: pair
+// blockIdx.y votes with the correspondences its RANSAC kept (mask), read in the
+// normalised form the essential-matrix problem already holds ((u-cx)/fx, the
+// very values pose_vote_kernel computes from the pixels).  A pair whose
+// args[].dist is negative has no model and is skipped.  votes: [pairs][4], zeroed
+// by the caller.
+__global__ __launch_bounds__(256) void pose_vote_pairs_kernel(const RansacProb* __restrict__ probs,
+                                                              const PoseVoteArgs* __restrict__ args,
+                                                              int32_t* __restrict__ votes)
+{
+    __shared__ int32_t s_votes[4];
+    const RansacProb pb = probs[blockIdx.y];
+    const int n = *pb.n_ptr;
+    if (blockIdx.x * 256 >= n) return;
+    const PoseVoteArgs pa = args[blockIdx.y];
+    if (pa.dist < 0) return;
+    if (threadIdx.x < 4) s_votes[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned f = 0;
+    if (i < n && pb.mask[i]) {
+        const double x1 = pb.x1[2 * i], y1 = pb.x1[2 * i + 1], x2 = pb.x2[2 * i], y2 = pb.x2[2 * i + 1];
+        const double bb = (x2 * x2 + y2 * y2) + 1.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double sg = k < 2 ? 1.0 : -1.0;
+            f |= (unsigned)cheirality_vote(pa.R[k & 1], sg * pa.t[0], sg * pa.t[1], sg * pa.t[2], x1, y1, x2, y2,
+                                           bb, pa.dist)
+                 << k;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long b = __ballot((f >> k) & 1);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&s_votes[k], __popcll(b));
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_votes[threadIdx.x]) atomicAdd(&votes[4 * blockIdx.y + threadIdx.x], s_votes[threadIdx.x]);
+}
+
+// models[p][9] = the model the selection kernel left for problem p
+__global__ __launch_bounds__(64) void gather_models_kernel(const RansacProb* __restrict__ probs, double* __restrict__ models)
+{
+    if (threadIdx.x < 9) models[9 * blockIdx.x + threadIdx.x] = probs[blockIdx.x].model_out[threadIdx.x];
 }
 
 // A = U diag(S) V^T of a row-major 3x3 matrix by one-sided Jacobi rotations of
@@ -158,6 +207,81 @@ static bool decompose_essential(const double* E, double* R1, double* R2, double*
     return true;
 }
 
+// OpenCV's order of preference: the first candidate not beaten by another.
+static int best_candidate(const int32_t* votes)
+{
+    for (int k = 0; k < 4; k++) {
+        bool top = true;
+        for (int j = 0; j < 4; j++) top = top && votes[k] >= votes[j];
+        if (top) return k;
+    }
+    return 3;
+}
+
+// recoverPose for the g pairs of the group sfm_gpu_match_pairs has just finished
+// (stream drained): each pair's RANSAC model against that pair's inliers.
+int pose_for_pairs(sfm_gpu_ctx* ctx, const RansacProb* dprobs, int g, const int32_t* n_inliers, const double* K,
+                   double distance_thresh, double* models_out, double* R_out, double* t_out, int32_t* n_pose_good,
+                   int nq_max)
+{
+    hipStream_t s = ctx->stream;
+    const size_t args_b = sizeof(PoseVoteArgs) * (size_t)g;
+    const size_t dev_b = args_b + (size_t)g * 72 + (size_t)g * 16;
+    SFM_HIP(ctx, ctx->pose_in.reserve(dev_b));
+    SFM_HIP(ctx, ctx->pin_a.reserve(dev_b));
+    char* dbase = ctx->pose_in.as<char>();
+    PoseVoteArgs* dargs = (PoseVoteArgs*)dbase;
+    double* dmodels = (double*)(dbase + args_b);
+    int32_t* dvotes = (int32_t*)(dbase + args_b + (size_t)g * 72);
+    char* hbase = ctx->pin_a.as<char>();
+    PoseVoteArgs* hargs = (PoseVoteArgs*)hbase;
+    double* hmodels = (double*)(hbase + args_b);
+    int32_t* hvotes = (int32_t*)(hbase + args_b + (size_t)g * 72);
+    gather_models_kernel<<<g, 64, 0, s>>>(dprobs, dmodels);
+    SFM_HIP(ctx, hipGetLastError());
+    SFM_HIP(ctx, hipMemcpyAsync(hmodels, dmodels, (size_t)g * 72, hipMemcpyDeviceToHost, s));
+    SFM_HIP(ctx, hipStreamSynchronize(s));
+    for (int i = 0; i < g; ++i) {
+        PoseVoteArgs& pa = hargs[i];
+        std::memset(&pa, 0, sizeof(pa));
+        pa.dist = -1.0;
+        if (n_inliers[i] <= 0) {
+            std::memset(hmodels + 9 * i, 0, 72);
+            continue;
+        }
+        if (!decompose_essential(hmodels + 9 * i, pa.R[0], pa.R[1], pa.t)) continue;
+        pa.fx = K[0];
+        pa.fy = K[4];
+        pa.cx = K[2];
+        pa.cy = K[5];
+        pa.dist = distance_thresh;
+    }
+    SFM_HIP(ctx, hipMemcpyAsync(dargs, hargs, args_b, hipMemcpyHostToDevice, s));
+    SFM_HIP(ctx, hipMemsetAsync(dvotes, 0, (size_t)g * 16, s));
+    {
+        ProfScope ps(ctx, "pose_vote");
+        pose_vote_pairs_kernel<<<dim3((nq_max + 255) / 256 > 0 ? (nq_max + 255) / 256 : 1, g), 256, 0, s>>>(dprobs, dargs, dvotes);
+        SFM_HIP(ctx, hipGetLastError());
+    }
+    SFM_HIP(ctx, hipMemcpyAsync(hvotes, dvotes, (size_t)g * 16, hipMemcpyDeviceToHost, s));
+    SFM_HIP(ctx, hipStreamSynchronize(s));
+    for (int i = 0; i < g; ++i) {
+        const PoseVoteArgs& pa = hargs[i];
+        if (models_out) std::memcpy(models_out + 9 * i, hmodels + 9 * i, 72);
+        if (pa.dist < 0) {
+            std::memset(R_out + 9 * i, 0, 72);
+            std::memset(t_out + 3 * i, 0, 24);
+            n_pose_good[i] = -1;
+            continue;
+        }
+        const int best = best_candidate(hvotes + 4 * i);
+        std::memcpy(R_out + 9 * i, pa.R[best & 1], 72);
+        for (int k = 0; k < 3; k++) t_out[3 * i + k] = best < 2 ? pa.t[k] : -pa.t[k];
+        n_pose_good[i] = hvotes[4 * i + best];
+    }
+    return SFM_GPU_OK;
+}
+
 }  // namespace sfm
 
 using namespace sfm;
@@ -214,13 +338,7 @@ extern "C" int sfm_gpu_recover_pose(sfm_gpu_ctx* ctx, const double* E, const dou
         std::memcpy(votes, ctx->pin_b.p, sizeof(votes));
         flags_host = ctx->pin_b.as<uint8_t>() + 16;
     }
-    // OpenCV's order of preference: the first candidate not beaten by another.
-    int best = 3;
-    for (int k = 0; k < 4 && best == 3; k++) {
-        bool top = true;
-        for (int j = 0; j < 4; j++) top = top && votes[k] >= votes[j];
-        if (top) best = k;
-    }
+    const int best = best_candidate(votes);
     std::memcpy(R_out, pa.R[best & 1], 9 * sizeof(double));
     for (int i = 0; i < 3; i++) t_out[i] = best < 2 ? pa.t[i] : -pa.t[i];
     if (mask)

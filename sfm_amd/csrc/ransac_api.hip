@@ -685,11 +685,17 @@ static void mp_collect(sfm_gpu_ctx* ctx, const int32_t* res, int g, int32_t* n_g
     }
 }
 
-int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images, const int32_t* pairs,
-                        int n_pairs, const sfm_gpu_match_params* params, int32_t* n_good,
-                        int32_t* n_inliers, sfm_gpu_dmatch* inlier_matches, int match_capacity)
+// What sfm_gpu_match_pairs_pose adds to sfm_gpu_match_pairs.
+struct PoseOut {
+    double distance_thresh;
+    double *models, *R, *t;
+    int32_t* n_pose_good;
+};
+
+static int match_pairs_impl(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images, const int32_t* pairs,
+                            int n_pairs, const sfm_gpu_match_params* params, int32_t* n_good, int32_t* n_inliers,
+                            sfm_gpu_dmatch* inlier_matches, int match_capacity, const PoseOut* pose)
 {
-    if (!ctx) return SFM_GPU_ERR_ARG;
     if (n_pairs < 0 || n_images < 0 || !params ||
         (n_pairs > 0 && (!images || !pairs || !n_good || !n_inliers)))
         return ctx->fail(SFM_GPU_ERR_ARG, "null pointer or negative count");
@@ -721,8 +727,42 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
                                                 hipMemcpyDeviceToHost, s));
             SFM_HIP(ctx, hipStreamSynchronize(s));
         }
+        if (pose) {
+            // the group's problem descriptors are still on the device (pds[0].prob is the first)
+            rc = pose_for_pairs(ctx, pds[0].prob, g, n_inliers + g0, params->K, pose->distance_thresh,
+                                pose->models ? pose->models + 9 * (size_t)g0 : nullptr, pose->R + 9 * (size_t)g0,
+                                pose->t + 3 * (size_t)g0, pose->n_pose_good + g0, pl.nq_max);
+            if (rc) return rc;
+        }
     }
     return SFM_GPU_OK;
+}
+
+int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images, const int32_t* pairs,
+                        int n_pairs, const sfm_gpu_match_params* params, int32_t* n_good,
+                        int32_t* n_inliers, sfm_gpu_dmatch* inlier_matches, int match_capacity)
+{
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    return match_pairs_impl(ctx, images, n_images, pairs, n_pairs, params, n_good, n_inliers, inlier_matches,
+                            match_capacity, nullptr);
+}
+
+int sfm_gpu_match_pairs_pose(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images, const int32_t* pairs,
+                             int n_pairs, const sfm_gpu_match_params* params, int32_t* n_good,
+                             int32_t* n_inliers, sfm_gpu_dmatch* inlier_matches, int match_capacity,
+                             double distance_thresh, double* models_out, double* R_out, double* t_out,
+                             int32_t* n_pose_good)
+{
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    if (n_pairs > 0 && (!R_out || !t_out || !n_pose_good))
+        return ctx->fail(SFM_GPU_ERR_ARG, "sfm_gpu_match_pairs_pose: null pose output");
+    if (params && params->model != SFM_GPU_MODEL_ESSENTIAL)
+        return ctx->fail(SFM_GPU_ERR_ARG, "sfm_gpu_match_pairs_pose: recoverPose needs the essential model");
+    if (!(distance_thresh >= 0))
+        return ctx->fail(SFM_GPU_ERR_ARG, "sfm_gpu_match_pairs_pose: distance_thresh must be >= 0");
+    const PoseOut po = {distance_thresh, models_out, R_out, t_out, n_pose_good};
+    return match_pairs_impl(ctx, images, n_images, pairs, n_pairs, params, n_good, n_inliers, inlier_matches,
+                            match_capacity, &po);
 }
 
 int sfm_gpu_match_pairs_begin(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images,

@@ -4,6 +4,8 @@
 
 #include "sfm_internal.h"
 
+struct sfm_gpu_ctx;
+
 namespace sfm {
 
 // slots of RansacProb::result (int32)
@@ -150,4 +152,10 @@ hipError_t launch_inlier_compact(hipStream_t s, const PairDev* pairs, int n_pair
 hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp,
                                 const PairDev* pairs);
 
+
+// recoverPose for the g problems at dprobs (essential model, stream drained,
+// masks final): pose.hip.  Pairs with n_inliers[i] <= 0 get n_pose_good = -1.
+int pose_for_pairs(sfm_gpu_ctx* ctx, const RansacProb* dprobs, int g, const int32_t* n_inliers, const double* K,
+                   double distance_thresh, double* models_out, double* R_out, double* t_out, int32_t* n_pose_good,
+                   int nq_max);
 }  // namespace sfm

@@ -384,6 +384,59 @@ def match_pairs(ctx, images, pairs, K, ratio=0.7, model=MODEL_ESSENTIAL, mode=RA
     return n_good, n_inl
 
 
+def match_pairs_pose(ctx, images, pairs, K, ratio=0.7, mode=RANSAC_ADAPTIVE, prob=0.99, threshold=1.0,
+                     max_iters=1000, n_hyp=0, distanceThresh=50.0, want_matches=False):
+    """match_pairs (essential model) followed per pair by recoverPose on the
+    pair's inlier matches with the pair's own essential matrix (main.cpp:400-420
+    for every pair instead of the first).  Returns a dict: n_good, n_inliers,
+    E [n,3,3], R [n,3,3], t [n,3], n_pose_good [n] (-1: no model), and
+    inlier_matches when asked for."""
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    n_pairs = pairs.shape[0]
+    arr = (ctypes.c_void_p * len(images))(*[im.handle for im in images])
+    p = _match_params(K, ratio, MODEL_ESSENTIAL, mode, prob, threshold, max_iters, n_hyp)
+    n_good = np.zeros(n_pairs, dtype=np.int32)
+    n_inl = np.zeros(n_pairs, dtype=np.int32)
+    E = np.zeros((n_pairs, 3, 3))
+    R = np.zeros((n_pairs, 3, 3))
+    t = np.zeros((n_pairs, 3))
+    n_pose = np.zeros(n_pairs, dtype=np.int32)
+    cap = 0
+    out = None
+    if want_matches:
+        cap = max([images[i].n for i in pairs[:, 0]] + [1])
+        out = np.zeros((n_pairs, cap), dtype=DMATCH_DTYPE)
+    ctx.check(ctx._L.sfm_gpu_match_pairs_pose(ctx.handle, arr, len(images), ptr(pairs), n_pairs, ctypes.byref(p),
+                                              ptr(n_good), ptr(n_inl), ptr(out), cap, float(distanceThresh),
+                                              ptr(E), ptr(R), ptr(t), ptr(n_pose)))
+    res = dict(n_good=n_good, n_inliers=n_inl, E=E, R=R, t=t, n_pose_good=n_pose)
+    if want_matches:
+        res["inlier_matches"] = [out[i, :n_inl[i]].copy() for i in range(n_pairs)]
+    return res
+
+
+def track_join_sequence(ctx, match_lists, capacity=None):
+    """The joins of main.cpp:432-456 for a whole sequence in one call: list l
+    against list l+1.  Returns a list of len(match_lists)-1 arrays [n, 3]."""
+    lists = [np.ascontiguousarray(m, dtype=DMATCH_DTYPE).reshape(-1) for m in match_lists]
+    n_lists = len(lists)
+    sizes = np.array([len(m) for m in lists], dtype=np.int32)
+    mcap = int(max([1] + [len(m) for m in lists]))
+    packed = np.zeros((max(n_lists, 1), mcap), dtype=DMATCH_DTYPE)
+    for l, m in enumerate(lists):
+        packed[l, :len(m)] = m
+    if capacity is None:
+        capacity = int(max(1, sizes[:-1].sum())) if n_lists > 1 else 1
+    out = np.zeros((capacity, 3), dtype=np.int32)
+    offs = np.zeros(max(n_lists, 1), dtype=np.int32)
+    rc = ctx._L.sfm_gpu_track_join_sequence(ctx.handle, ptr(packed), ptr(sizes), mcap, n_lists, ptr(out), capacity,
+                                            ptr(offs))
+    if rc == _lib.ERR_CAPACITY and n_lists > 1 and capacity < offs[n_lists - 1]:
+        return track_join_sequence(ctx, lists, capacity=int(offs[n_lists - 1]))
+    ctx.check(rc)
+    return [out[offs[l]:offs[l + 1]].copy() for l in range(n_lists - 1)]
+
+
 # ---- images in caller-owned device memory ---------------------------------
 
 def image_packed_bytes(n):

@@ -280,6 +280,68 @@ def trial_tracks(ctx, rng, idx, stats):
     return 0
 
 
+def trial_sequence(ctx, rng, idx, stats):
+    """Joins of a whole sequence in one call against the loop per image."""
+    n_lists = int(rng.choice([0, 1, 2, 3, 7]))
+    kp = int(rng.choice([5, 300, 6000]))
+    ls = []
+    for l in range(n_lists):
+        n = int(rng.choice([0, 1, 40, 1024, 2500]))
+        m = np.zeros(n, matcher.DMATCH_DTYPE)
+        m["queryIdx"] = np.sort(rng.integers(0, kp, n))
+        m["trainIdx"] = rng.integers(0, kp, n)
+        ls.append(m)
+    got = matcher.track_join_sequence(ctx, ls)
+    stats["sequence"] += 1
+    bad = len(got) != max(n_lists - 1, 0)
+    for l in range(n_lists - 1):
+        want = oracle.track_join(ls[l], ls[l + 1])
+        bad = bad or got[l].shape != want.shape or not (got[l] == want).all()
+    if bad:
+        path = save_failure("sequence", idx, **{"l%d" % l: m for l, m in enumerate(ls)})
+        print("MISMATCH sequence #%d lists %s -> %s" % (idx, [len(m) for m in ls], path), flush=True)
+        return 1
+    return 0
+
+
+def trial_pnp(ctx, rng, idx, stats):
+    """solvePnPRansac on planted poses: general, planar and repeated object
+    points, 0-90 % wrong correspondences, odd parameters."""
+    n = int(rng.choice([5, 6, 7, 12, 60, 400, 3000]))
+    kind = str(rng.choice(["general", "planar", "repeated"]))
+    X = np.stack([rng.uniform(-300, 300, n), rng.uniform(-200, 200, n), rng.uniform(500, 1100, n)], 1)
+    if kind == "planar":
+        X[:, 2] = 800.0 + 0.05 * X[:, 0]
+    if kind == "repeated" and n > 6:
+        X[n // 2:] = X[:n - n // 2]
+    R = _rot(rng, 25.0)
+    t = np.array([rng.normal(0, 30), rng.normal(0, 30), rng.normal(0, 60)])
+    Xc = X @ R.T + t
+    u = (Xc @ synth.REF_K.T)
+    u = u[:, :2] / u[:, 2:]
+    u += rng.normal(0, float(rng.choice([0.0, 0.3, 2.0])), u.shape)
+    wrong = rng.uniform(size=n) < float(rng.choice([0.0, 0.1, 0.4, 0.9]))
+    u[wrong] = np.stack([rng.uniform(0, synth.IMG_W, wrong.sum()), rng.uniform(0, synth.IMG_H, wrong.sum())], 1)
+    iters = int(rng.choice([1, 10, 100, 300]))
+    err = float(rng.choice([0.5, 2.0, 8.0, 30.0]))
+    conf = float(rng.choice([0.5, 0.99, 0.999999]))
+    ok, rvec, tvec, _, info = matcher.solvePnPRansac(ctx, X, u, synth.REF_K, iterationsCount=iters,
+                                                     reprojectionError=err, confidence=conf)
+    o = oracle.pnp_ransac(X, u, synth.REF_K, iterations_count=iters, reprojection_error=err, confidence=conf)
+    stats["pnp"] += 1
+    same = bool(ok) == bool(o["ok"])
+    if same and o["ok"]:
+        same = (info["iters"] == o["iters"] and info["n_inliers"] == o["n_inliers"] and
+                (info["mask"] == o["mask"]).all() and info["R"].tobytes() == o["R"].tobytes() and
+                tvec.tobytes() == o["tvec"].tobytes() and rvec.tobytes() == o["rvec"].tobytes())
+    if not same:
+        path = save_failure("pnp", idx, X=X, u=u, iters=iters, err=err, conf=conf)
+        print("MISMATCH pnp #%d n=%d %s iters=%d err=%g conf=%g: ok %d/%d -> %s"
+              % (idx, n, kind, iters, err, conf, ok, o["ok"], path), flush=True)
+        return 1
+    return 0
+
+
 def run(seconds, seed, only="", ctx=None, quiet=False):
     """Draws trials for `seconds`; returns (fails, trials, stats)."""
     rng = np.random.default_rng(seed)
@@ -287,9 +349,9 @@ def run(seconds, seed, only="", ctx=None, quiet=False):
     if own:
         ctx = matcher.Context(0)
     bf = matcher.BFMatcher(ctx)
-    stats = dict(ransac=0, ransac_ok=0, model_last_bits=0, pose=0, knn=0, pairs=0, tracks=0)
+    stats = dict(ransac=0, ransac_ok=0, model_last_bits=0, pose=0, knn=0, pairs=0, tracks=0, sequence=0, pnp=0)
     only = [s for s in only.split(",") if s]
-    menu = [("ransac", 6), ("knn", 2), ("pairs", 1), ("tracks", 1)]
+    menu = [("ransac", 6), ("knn", 2), ("pairs", 1), ("tracks", 1), ("sequence", 0.5), ("pnp", 1)]
     menu = [(k, w) for k, w in menu if not only or k in only]
     names = [k for k, _ in menu]
     weights = np.array([w for _, w in menu], float)
@@ -306,6 +368,10 @@ def run(seconds, seed, only="", ctx=None, quiet=False):
             fails += trial_knn(ctx, bf, rng, idx, stats)
         elif what == "pairs":
             fails += trial_pairs(ctx, rng, idx, stats)
+        elif what == "sequence":
+            fails += trial_sequence(ctx, rng, idx, stats)
+        elif what == "pnp":
+            fails += trial_pnp(ctx, rng, idx, stats)
         else:
             fails += trial_tracks(ctx, rng, idx, stats)
         idx += 1
@@ -321,7 +387,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--only", default="", help="comma list of ransac,knn,pairs,tracks")
+    ap.add_argument("--only", default="", help="comma list of ransac,knn,pairs,tracks,sequence,pnp")
     args = ap.parse_args()
     fails, idx, stats = run(args.seconds, args.seed, args.only)
     print("done: trials=%d fails=%d %s" % (idx, fails, stats), flush=True)
