@@ -34,6 +34,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -152,6 +153,8 @@ def main():
                     help="descriptors arrive as CV_8U instead of cv::SIFT's CV_32F (not the headline configuration)")
     ap.add_argument("--no-configs2", action="store_true", help="skip the 32768 x 32768 pair block")
     ap.add_argument("--no-allpairs", action="store_true", help="skip the exhaustive-matching block")
+    ap.add_argument("--extras-deadline", type=int, default=420,
+                    help="seconds the blocks after the timed region may take before the line is printed without them")
     ap.add_argument("--allpairs-views", type=int, default=64)
     ap.add_argument("--allpairs-desc", type=int, default=20000)
     args = ap.parse_args()
@@ -412,107 +415,7 @@ def main():
         elapsed = float(t.item())
     joined = dist.get_world_size() if world > 1 else 1
 
-    # ---- BASELINE configs[2]: one 32768 x 32768 pair + essential RANSAC, 4096 hypotheses
-    # (outside the timed region; rank 0 of a single-GPU run only)
-    configs2 = None
-    if rank == 0 and world == 1 and not args.no_configs2:
-        from sfm_amd import synth
-        n2, nh2 = 32768, 4096
-        Q2, T2, planted2 = synth.planted_pair(n2, n2, 1101, 1102, 1103)
-        kq2, kt2 = synth.keypoints_for_pair(n2, n2, planted2, 2101, wrong_frac=args.wrong_frac)
-        with torch.cuda.stream(stream):
-            d2 = torch.from_numpy(np.stack([Q2, T2])).cuda()
-            k2 = torch.from_numpy(np.stack([kq2, kt2])).cuda()
-            blk2 = matcher.image_packed_bytes(n2)
-            pk2 = torch.empty((2, blk2), dtype=torch.uint8, device="cuda")
-        stream.synchronize()
-        matcher.prepare_many(ctx, [d2[i].data_ptr() for i in range(2)], [n2, n2], 512, matcher.DESC_F32,
-                             [k2[i].data_ptr() for i in range(2)], [pk2[i].data_ptr() for i in range(2)])
-        matcher.check_inputs(ctx)
-        im2 = [matcher.WrappedImage(ctx, pk2[i].data_ptr(), n2) for i in range(2)]
-        one = np.array([[0, 1]], np.int32)
-        kw2 = dict(ratio=0.7, model=matcher.MODEL_ESSENTIAL, mode=matcher.RANSAC_FIXED, prob=0.99, threshold=1.0,
-                   n_hyp=nh2)
-        from sfm_amd import synth as _synth
-        for _ in range(3):
-            g2, i2 = matcher.match_pairs(ctx, im2, one, _synth.REF_K, **kw2)
-        ctx.profile_select(None)
-        ctx.profile_enable(True)
-        ctx.profile_reset()
-        reps2 = 10
-        t2 = time.perf_counter()
-        for _ in range(reps2):
-            g2, i2 = matcher.match_pairs(ctx, im2, one, _synth.REF_K, **kw2)
-        ctx.synchronize()
-        wall2 = (time.perf_counter() - t2) / reps2
-        k2us = {}
-        for name in ("knn2_mfma", "knn_finalize", "ransac_solve", "ransac_score", "ransac_select"):
-            ms, cnt = ctx.profile_query(name)
-            if cnt:
-                k2us[name] = round(ms / cnt * 1e3, 2)
-        ctx.profile_enable(False)
-        ops2 = 2.0 * n2 * n2 * 128
-        configs2 = {
-            "workload": "configs[2]: one pair of %dx%d descriptors, kNN k=2 + ratio 0.7 + five-point essential "
-                        "RANSAC %d hyps (fixed count)" % (n2, n2, nh2),
-            "knn2_mfma_us": k2us.get("knn2_mfma"),
-            "knn2_mfma_frac_of_int8_peak": round(ops2 / (k2us["knn2_mfma"] * 1e-6) / 1e12 / INT8_DENSE_PEAK_TOPS, 4)
-            if k2us.get("knn2_mfma") else None,
-            "five_point_solve_us": k2us.get("ransac_solve"),
-            "scoring_us": k2us.get("ransac_score"),
-            "neighbour_extraction_us": k2us.get("knn_finalize"),
-            "ms_per_pair_host_clock": round(wall2 * 1e3, 3),
-            "n_good": int(g2[0]), "n_inliers": int(i2[0]),
-            "what": "HIP events around each launch of the one-pair call (one sweep launch of 512 workgroups), "
-                    "average of %d calls, measured after the timed region" % reps2,
-        }
-        for im in im2:
-            im.close()
-        del d2, k2, pk2
-
-    # ---- BASELINE configs[3]: exhaustive matching of V views, sharded over the ranks (strong scaling)
-    allp = None
-    if not args.no_allpairs:
-        from sfm_amd import allpairs, synth
-        V, nd = args.allpairs_views, args.allpairs_desc
-        lo, hi = allpairs.owned_range(V, world, rank)
-        descs_v, kps_v, _ = synth.image_sequence(hi, nd, 4242, shared=0.4)   # images lo..hi-1 are this rank's
-        with torch.cuda.stream(stream):
-            local = [(torch.from_numpy(descs_v[i]).cuda(), torch.from_numpy(kps_v[i]).cuda()) for i in range(lo, hi)]
-        stream.synchronize()
-        del descs_v, kps_v
-        be = allpairs.GpuBackend(ctx, K=synth.REF_K, model=matcher.MODEL_ESSENTIAL, mode=matcher.RANSAC_ADAPTIVE,
-                                 prob=0.99, threshold=1.0, max_iters=1000)
-        dev = torch.device("cuda", local_rank)
-        best = None
-        with torch.cuda.stream(stream):
-            for rep in range(3):   # the first run sizes the workspaces
-                fence()
-                t3 = time.perf_counter()
-                ap_pairs, ap_good, ap_inl, ap_stats = allpairs.match_all_pairs(local, V, be, mode="all", device=dev,
-                                                                             return_stats=True)
-                fence()
-                dt3 = time.perf_counter() - t3
-                if world > 1:
-                    tt = torch.tensor([dt3], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    dt3 = float(tt.item())
-                if rep > 0:
-                    best = dt3 if best is None else min(best, dt3)
-        adj = [int(ap_inl[i, i + 1]) for i in range(V - 1)]
-        allp = {
-            "workload": "configs[3]: %d views x %d descriptors, all %d pairs, kNN k=2 + ratio 0.7 + essential RANSAC "
-                        "(adaptive, prob 0.99, 1 px), descriptors resident in HBM as float32" % (V, nd, len(ap_pairs)),
-            "scaling": "strong", "n_gpus": joined, "pairs": int(len(ap_pairs)),
-            "seconds": round(best, 5), "pairs_per_s": round(len(ap_pairs) / best, 1),
-            "includes": "descriptor conversion where the images live, all-gather of the prepared images, dealt pair "
-                        "list, matching, all-reduce of the V x V count matrices (max over ranks, best of 2 runs)",
-            "gathered_bytes_per_rank": ap_stats["gathered_bytes"], "collective_backend": backend if world > 1 else None,
-            "inliers_neighbouring_views_min_max": [min(adj), max(adj)] if adj else None,
-            "inliers_farthest_pair": int(ap_inl[0, V - 1]) if V > 1 else None,
-        }
-        del local
-
+    out = {}
     if rank == 0:
         total_pairs = B * args.steps * world
         value = total_pairs / elapsed
@@ -610,13 +513,138 @@ def main():
                 "note": "the equivalent rate exceeds the FP64 peak because the exact staged bound scores most "
                         "models on a fraction of the points; counters for this kernel: profiles/",
             }
+    # The further blocks (outside the timed region) run under a deadline: if one of
+    # them hangs or fails on any rank -- a collective that never completes, a rank
+    # that ran out of memory -- every rank leaves when the deadline passes and rank 0
+    # still prints the line it has, so the headline measurement is never lost to an
+    # auxiliary block.
+    def give_up():
+        if rank == 0:
+            out["extras_incomplete"] = "deadline of %d s passed in: %s" % (args.extras_deadline, stage[0])
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    stage = ["start"]
+    watchdog = threading.Timer(args.extras_deadline, give_up)
+    watchdog.daemon = True
+    watchdog.start()
+    configs2 = allp = None
+    try:
+        # ---- BASELINE configs[2]: one 32768 x 32768 pair + essential RANSAC, 4096 hypotheses
+        # (outside the timed region; rank 0 of a single-GPU run only)
+        stage[0] = "configs2"
+        if rank == 0 and world == 1 and not args.no_configs2:
+            from sfm_amd import synth
+            n2, nh2 = 32768, 4096
+            Q2, T2, planted2 = synth.planted_pair(n2, n2, 1101, 1102, 1103)
+            kq2, kt2 = synth.keypoints_for_pair(n2, n2, planted2, 2101, wrong_frac=args.wrong_frac)
+            with torch.cuda.stream(stream):
+                d2 = torch.from_numpy(np.stack([Q2, T2])).cuda()
+                k2 = torch.from_numpy(np.stack([kq2, kt2])).cuda()
+                blk2 = matcher.image_packed_bytes(n2)
+                pk2 = torch.empty((2, blk2), dtype=torch.uint8, device="cuda")
+            stream.synchronize()
+            matcher.prepare_many(ctx, [d2[i].data_ptr() for i in range(2)], [n2, n2], 512, matcher.DESC_F32,
+                                 [k2[i].data_ptr() for i in range(2)], [pk2[i].data_ptr() for i in range(2)])
+            matcher.check_inputs(ctx)
+            im2 = [matcher.WrappedImage(ctx, pk2[i].data_ptr(), n2) for i in range(2)]
+            one = np.array([[0, 1]], np.int32)
+            kw2 = dict(ratio=0.7, model=matcher.MODEL_ESSENTIAL, mode=matcher.RANSAC_FIXED, prob=0.99, threshold=1.0,
+                       n_hyp=nh2)
+            from sfm_amd import synth as _synth
+            for _ in range(3):
+                g2, i2 = matcher.match_pairs(ctx, im2, one, _synth.REF_K, **kw2)
+            ctx.profile_select(None)
+            ctx.profile_enable(True)
+            ctx.profile_reset()
+            reps2 = 10
+            t2 = time.perf_counter()
+            for _ in range(reps2):
+                g2, i2 = matcher.match_pairs(ctx, im2, one, _synth.REF_K, **kw2)
+            ctx.synchronize()
+            wall2 = (time.perf_counter() - t2) / reps2
+            k2us = {}
+            for name in ("knn2_mfma", "knn_finalize", "ransac_solve", "ransac_score", "ransac_select"):
+                ms, cnt = ctx.profile_query(name)
+                if cnt:
+                    k2us[name] = round(ms / cnt * 1e3, 2)
+            ctx.profile_enable(False)
+            ops2 = 2.0 * n2 * n2 * 128
+            configs2 = {
+                "workload": "configs[2]: one pair of %dx%d descriptors, kNN k=2 + ratio 0.7 + five-point essential "
+                            "RANSAC %d hyps (fixed count)" % (n2, n2, nh2),
+                "knn2_mfma_us": k2us.get("knn2_mfma"),
+                "knn2_mfma_frac_of_int8_peak": round(ops2 / (k2us["knn2_mfma"] * 1e-6) / 1e12 / INT8_DENSE_PEAK_TOPS, 4)
+                if k2us.get("knn2_mfma") else None,
+                "five_point_solve_us": k2us.get("ransac_solve"),
+                "scoring_us": k2us.get("ransac_score"),
+                "neighbour_extraction_us": k2us.get("knn_finalize"),
+                "ms_per_pair_host_clock": round(wall2 * 1e3, 3),
+                "n_good": int(g2[0]), "n_inliers": int(i2[0]),
+                "what": "HIP events around each launch of the one-pair call (one sweep launch of 512 workgroups), "
+                        "average of %d calls, measured after the timed region" % reps2,
+            }
+            for im in im2:
+                im.close()
+            del d2, k2, pk2
+
+        # ---- BASELINE configs[3]: exhaustive matching of V views, sharded over the ranks (strong scaling)
+        stage[0] = "allpairs"
+        if not args.no_allpairs:
+            from sfm_amd import allpairs, synth
+            V, nd = args.allpairs_views, args.allpairs_desc
+            lo, hi = allpairs.owned_range(V, world, rank)
+            descs_v, kps_v, _ = synth.image_sequence(hi, nd, 4242, shared=0.4)   # images lo..hi-1 are this rank's
+            with torch.cuda.stream(stream):
+                local = [(torch.from_numpy(descs_v[i]).cuda(), torch.from_numpy(kps_v[i]).cuda()) for i in range(lo, hi)]
+            stream.synchronize()
+            del descs_v, kps_v
+            be = allpairs.GpuBackend(ctx, K=synth.REF_K, model=matcher.MODEL_ESSENTIAL, mode=matcher.RANSAC_ADAPTIVE,
+                                     prob=0.99, threshold=1.0, max_iters=1000)
+            dev = torch.device("cuda", local_rank)
+            best = None
+            with torch.cuda.stream(stream):
+                for rep in range(3):   # the first run sizes the workspaces
+                    fence()
+                    t3 = time.perf_counter()
+                    ap_pairs, ap_good, ap_inl, ap_stats = allpairs.match_all_pairs(local, V, be, mode="all", device=dev,
+                                                                                 return_stats=True)
+                    fence()
+                    dt3 = time.perf_counter() - t3
+                    if world > 1:
+                        tt = torch.tensor([dt3], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                        dt3 = float(tt.item())
+                    if rep > 0:
+                        best = dt3 if best is None else min(best, dt3)
+            adj = [int(ap_inl[i, i + 1]) for i in range(V - 1)]
+            allp = {
+                "workload": "configs[3]: %d views x %d descriptors, all %d pairs, kNN k=2 + ratio 0.7 + essential RANSAC "
+                            "(adaptive, prob 0.99, 1 px), descriptors resident in HBM as float32" % (V, nd, len(ap_pairs)),
+                "scaling": "strong", "n_gpus": joined, "pairs": int(len(ap_pairs)),
+                "seconds": round(best, 5), "pairs_per_s": round(len(ap_pairs) / best, 1),
+                "includes": "descriptor conversion where the images live, all-gather of the prepared images, dealt pair "
+                            "list, matching, all-reduce of the V x V count matrices (max over ranks, best of 2 runs)",
+                "gathered_bytes_per_rank": ap_stats["gathered_bytes"], "collective_backend": backend if world > 1 else None,
+                "inliers_neighbouring_views_min_max": [min(adj), max(adj)] if adj else None,
+                "inliers_farthest_pair": int(ap_inl[0, V - 1]) if V > 1 else None,
+            }
+            del local
+
+    except Exception as e:  # noqa: BLE001 -- reported in the line; peers waiting in a collective meet the deadline
+        if rank == 0:
+            out["extras_error"] = "%s in %s: %s" % (type(e).__name__, stage[0], e)
+    if rank == 0:
         if configs2:
             out["configs2"] = configs2
         if allp:
             out["allpairs"] = allp
+    if world == 1:
+        watchdog.cancel()
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # the CPU leg belongs to the single-GPU line only
             threads = host_threads()
-            cb = cpu_baseline(descs, kps, nh, threads, min(B, 16))
+            cb = cpu_baseline(descs, kps, nh, threads, min(B, 64))
             out["cpu_baseline"] = {
                 "value": round(cb["n_pairs"] / cb["seconds"], 4),
                 "unit": "pairs/s",
@@ -629,9 +657,13 @@ def main():
                           (cb["n_pairs"], n, n, nh, threads, cb["knn_seconds"], cb["ransac_seconds"],
                            cb["n_inliers"], float(np.mean(n_inl[:cb["n_pairs"]]))),
             }
+    if world > 1:
+        stage[0] = "final barrier"
+        dist.barrier()
+    watchdog.cancel()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
     for im in images:
         im.close()
