@@ -503,9 +503,6 @@ knn2_mfma16_kernel(const KnnJob* __restrict__ jobs, int chunks_per_split, int qb
     uint32_t m1[QB], m2[QB], m3[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) m1[qb] = m2[qb] = m3[qb] = 0xFFFFFFFFu;
-#ifdef SFM_EXP_PRIO
-    if (WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
 
     // stage image in LDS and its DMA: as in the 32x32 kernel
     const int dma_r = lane >> 3;
@@ -825,18 +822,24 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
     const KnnJob job = jobs[wg.job];
     const u64 NONE = ~0ull;
     const uint32_t tmask = (1u << TILE_BITS) - 1u;
-    // Step 1, eight threads per query of the workgroup's 32: merge the query's
-    // records (one per split) into the two best groups and the third minimum,
-    // decide whether the query needs neighbours at all, and list those that do.
+    // Step 1, two or eight threads per query of the workgroup's 32: merge the
+    // query's records (one per train part and sweep lane) into the two best groups
+    // and the third minimum, decide whether the query needs neighbours at all, and
+    // list those that do.  The merge is all 64-bit compares: with few records per
+    // query two threads each (one wavefront for the 32 queries) issue a quarter of
+    // the instructions eight would; with many records eight shorten the chain.
     __shared__ u64 s_c[RESCAN_QPW][3];
     __shared__ int s_list[RESCAN_QPW];
     __shared__ int s_wcount[4];
     {
-        const int qi = threadIdx.x >> 3, part = threadIdx.x & 7;
+        const int n_rec = n_splits * SUBS;
+        const int tpq_log = n_rec >= 16 ? 3 : 1, tpq = 1 << tpq_log;
+        const bool worker = (int)threadIdx.x < tpq * RESCAN_QPW;  // whole wavefronts
+        const int qi = (threadIdx.x >> tpq_log) & (RESCAN_QPW - 1), part = threadIdx.x & (tpq - 1);
         const int q = wg.qblock * RESCAN_QPW + qi;
         bool need = false;
         u64 c1 = NONE, c2 = NONE, c3 = NONE;
-        if (q < job.n_query) {
+        if (worker && q < job.n_query) {
             // key = x << 32 | (unit << SB | sub): ascending (x, unit, sub)
             auto key_of = [&](uint32_t p, uint32_t t0, uint32_t sub) -> u64 {
                 return ((u64)(p >> TILE_BITS) << 32) | (((t0 + (p & tmask)) << SB) | sub);
@@ -844,7 +847,7 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
             // One record per (part, lane of the query in the sweep), its three groups
             // already in ascending order.  A lane's third group may be the second
             // best of all, so all three keep their identity.
-            for (int j = part; j < n_splits * SUBS; j += 8) {
+            for (int j = part; j < n_rec; j += tpq) {
                 const int sp = j / SUBS;
                 const uint32_t sub = (uint32_t)(j - sp * SUBS);
                 const uint4 r = job.partial[((size_t)sp * job.q_rows_alloc + q) * REC_SUBS + sub];
@@ -855,11 +858,13 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
                 merge3(c1, c2, c3, b1, b2, b3);
             }
         }
-        for (int off = 1; off < 8 && off < n_splits * SUBS; off <<= 1) {
-            const u64 b1 = __shfl_xor(c1, off), b2 = __shfl_xor(c2, off), b3 = __shfl_xor(c3, off);
-            merge3(c1, c2, c3, b1, b2, b3);
+        if (worker) {  // every lane of these wavefronts: a partner lane may hold a query past the end
+            for (int off = 1; off < tpq; off <<= 1) {
+                const u64 b1 = __shfl_xor(c1, off), b2 = __shfl_xor(c2, off), b3 = __shfl_xor(c3, off);
+                merge3(c1, c2, c3, b1, b2, b3);
+            }
         }
-        if (part == 0 && q < job.n_query) {
+        if (worker && part == 0 && q < job.n_query) {
             need = true;
             // Pipelines that only keep the queries passing the ratio test
             // d1 < r * d2 (skip_r2 = r^2 > 0) need no neighbours for a query that
