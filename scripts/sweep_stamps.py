@@ -37,6 +37,14 @@ def main():
     print("prologue us  ", q(pro / cm), " cycles med %d" % np.median(pro))
     print("stage loop us", q(loop / cm), " cycles med %d" % np.median(loop))
     print("epilogue us  ", q(epi / cm), " cycles med %d" % np.median(epi))
+    # does the position in the grid tell which workgroups run ahead?
+    lu = loop / cm
+    ids = np.arange(nwg)
+    print("loop us by grid half:   first %.1f  second %.1f" % (lu[ids < nwg // 2].mean(), lu[ids >= nwg // 2].mean()))
+    print("loop us by id parity:   even %.1f  odd %.1f" % (lu[ids % 2 == 0].mean(), lu[ids % 2 == 1].mean()))
+    print("loop us by (id/8) parity:  even %.1f  odd %.1f" % (lu[(ids // 8) % 2 == 0].mean(), lu[(ids // 8) % 2 == 1].mean()))
+    print("loop us by eighth of the grid:", " ".join("%.1f" % lu[(ids * 8) // nwg == e].mean() for e in range(8)))
+    print("fast (< median) workgroups per eighth:", " ".join("%d" % (lu[(ids * 8) // nwg == e] < np.median(lu)).sum() for e in range(8)))
     for x in range(8):
         sel = st[:, 6] == x
         if sel.any():
