@@ -197,3 +197,28 @@ def test_track_join_sequence_limits(gpu_ctx):
     rc = L.sfm_gpu_track_join_sequence(gpu_ctx.handle, matcher.ptr(packed), matcher.ptr(sizes_bad), 500, 3,
                                        matcher.ptr(big), 2000, matcher.ptr(offs))
     assert rc == _lib.ERR_ARG
+
+
+def test_match_pairs_pose_over_two_launch_groups(gpu_ctx):
+    """More pairs than one launch group holds (256): the poses of the second
+    group land at their own places and equal one-pair calls."""
+    rng = np.random.default_rng(32)
+    pool = synth.sift_like(600, 52)
+    images = []
+    for v in range(12):
+        n = 300 + 17 * v
+        d = np.clip(pool[rng.permutation(600)[:n]] + rng.integers(-3, 4, (n, 128)), 0, 255).astype(np.float32)
+        kp = np.stack([rng.uniform(0, synth.IMG_W, n), rng.uniform(0, synth.IMG_H, n)], 1).astype(np.float32)
+        images.append(matcher.Image(gpu_ctx, d, kp))
+    pairs = np.array([[i, j] for i in range(12) for j in range(12) if i != j] * 2, np.int32)[:261]
+    kw = dict(ratio=0.8, mode=matcher.RANSAC_FIXED, prob=0.99, threshold=3.0, n_hyp=32)
+    res = matcher.match_pairs_pose(gpu_ctx, images, pairs, synth.REF_K, **kw)
+    assert (res["n_pose_good"] >= 0).sum() > 200
+    for p in (0, 100, 255, 256, 260):
+        one = matcher.match_pairs_pose(gpu_ctx, images, pairs[p:p + 1], synth.REF_K, **kw)
+        for key in ("n_good", "n_inliers", "n_pose_good"):
+            assert one[key][0] == res[key][p]
+        for key in ("E", "R", "t"):
+            assert one[key][0].tobytes() == res[key][p].tobytes()
+    for im in images:
+        im.close()
