@@ -390,22 +390,26 @@ def main():
     # the timed region, for this one measurement.
     ceil_ms, ceil_cnt = 0.0, 0
     if not args.no_microkernel:
-        tctx = matcher.Context(local_rank, stream=stream.cuda_stream, timing_build=True)
-        timages = [matcher.WrappedImage(tctx, lanes[0].packed[0][i].data_ptr(), n) for i in range(2 * B)]
-        tctx.profile_select("knn2_mfma")
-        tctx.profile_enable(True)
-        tctx.check(tctx._L.sfm_gpu_debug_set_knn_variant(
-            tctx.handle, (args.knn_variant if args.knn_variant >= 0 else 4) + 16 * 7))
-        for it in range(5):
-            if it == 2:   # the first calls load the timing library's code objects and size its workspaces
-                tctx.profile_reset()
-            matcher.match_pairs(tctx, timages, pairs, None, ratio=0.7, model=matcher.MODEL_FUNDAMENTAL,
-                                mode=matcher.RANSAC_FIXED, prob=0.99, threshold=3.0, n_hyp=nh)
-        tctx.synchronize()
-        ceil_ms, ceil_cnt = tctx.profile_query("knn2_mfma")
-        for im in timages:
-            im.close()
-        tctx.close()
+        try:
+            tctx = matcher.Context(local_rank, stream=stream.cuda_stream, timing_build=True)
+            timages = [matcher.WrappedImage(tctx, lanes[0].packed[0][i].data_ptr(), n) for i in range(2 * B)]
+            tctx.profile_select("knn2_mfma")
+            tctx.profile_enable(True)
+            tctx.check(tctx._L.sfm_gpu_debug_set_knn_variant(
+                tctx.handle, (args.knn_variant if args.knn_variant >= 0 else 4) + 16 * 7))
+            for it in range(5):
+                if it == 2:   # the first calls load the timing library's code objects and size its workspaces
+                    tctx.profile_reset()
+                matcher.match_pairs(tctx, timages, pairs, None, ratio=0.7, model=matcher.MODEL_FUNDAMENTAL,
+                                    mode=matcher.RANSAC_FIXED, prob=0.99, threshold=3.0, n_hyp=nh)
+            tctx.synchronize()
+            ceil_ms, ceil_cnt = tctx.profile_query("knn2_mfma")
+            for im in timages:
+                im.close()
+            tctx.close()
+        except (OSError, RuntimeError) as e:   # no timing library in this tree: the line goes without the ceiling
+            print("mfma-only microkernel skipped: %s" % e, file=sys.stderr, flush=True)
+            ceil_ms, ceil_cnt = 0.0, 0
     ctx.profile_select(None)
     ctx.profile_enable(False)
 
@@ -480,7 +484,7 @@ def main():
                 "avg_launch_us": knn["avg_us"],
                 "mfma_only_microkernel": {
                     "what": "same launch with MFMAs + LDS fragment reads only, measured after the timed region",
-                    "avg_launch_us": round(ceil_ms / max(ceil_cnt, 1) * 1e3, 2),
+                    "avg_launch_us": round(ceil_ms / ceil_cnt * 1e3, 2) if ceil_cnt else None,
                     "frac_of_peak": round(ops_per_launch / (ceil_ms / max(ceil_cnt, 1) * 1e-3) / 1e12
                                           / INT8_DENSE_PEAK_TOPS, 4) if ceil_cnt else None,
                 },
