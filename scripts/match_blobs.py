@@ -59,19 +59,30 @@ def main():
     if args.fundamental:
         n_good, n_inl, sel = matcher.match_pairs(ctx, images, pairs, None, model=matcher.MODEL_FUNDAMENTAL,
                                                  prob=0.99, threshold=3.0, want_matches=True)
+        poses = None
     else:
-        n_good, n_inl, sel = matcher.match_pairs(ctx, images, pairs, K, prob=0.99, threshold=1.0, want_matches=True)
+        # with the pose of every pair from its own essential matrix (main.cpp:400-420 for each pair)
+        poses = matcher.match_pairs_pose(ctx, images, pairs, K, prob=0.99, threshold=1.0, want_matches=True)
+        n_good, n_inl, sel = poses["n_good"], poses["n_inliers"], poses["inlier_matches"]
     t1 = time.perf_counter()
     for (i, j), g, k in zip(pairs.tolist(), n_good, n_inl):
         print("pair %3d %3d: %6d x %6d descriptors, good matches %6d, inliers %6d" %
               (i, j, images[i].n, images[j].n, g, k))
     print("%d images, %d pairs: upload + match + RANSAC %.1f ms" % (V, len(pairs), (t1 - t0) * 1e3))
+    if poses is not None:
+        for p, (i, j) in enumerate(pairs.tolist()):
+            if poses["n_pose_good"][p] >= 0:
+                print("pair %3d %3d: %d of %d inliers in front of both cameras, t = %s" %
+                      (i, j, poses["n_pose_good"][p], n_inl[p], np.round(poses["t"][p], 3).tolist()))
     if not args.all_pairs:
-        for i in range(len(pairs) - 1):
-            if pairs[i][1] != pairs[i + 1][0]:
-                continue
-            tr = matcher.track_join(ctx, sel[i], sel[i + 1])
-            print("images %d-%d-%d: %d three-view tracks" % (pairs[i][0], pairs[i][1], pairs[i + 1][1], len(tr)))
+        # the ring's lists are consecutive pairs (i, i+1), (i+1, i+2): all joins in one call
+        t2 = time.perf_counter()
+        tracks = matcher.track_join_sequence(ctx, sel)
+        t3 = time.perf_counter()
+        for i, tr in enumerate(tracks):
+            if pairs[i][1] == pairs[i + 1][0]:
+                print("images %d-%d-%d: %d three-view tracks" % (pairs[i][0], pairs[i][1], pairs[i + 1][1], len(tr)))
+        print("%d joins in one call: %.2f ms" % (len(tracks), (t3 - t2) * 1e3))
     for im in images:
         im.close()
     ctx.close()
