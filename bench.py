@@ -534,7 +534,7 @@ def main():
     watchdog.start()
     configs2 = allp = None
     try:
-        # ---- BASELINE configs[2]: one 32768 x 32768 pair + essential RANSAC, 4096 hypotheses
+        # ---- the one-large-pair configuration: one 32768 x 32768 pair + essential RANSAC, 4096 hypotheses
         # (outside the timed region; rank 0 of a single-GPU run only)
         stage[0] = "configs2"
         if rank == 0 and world == 1 and not args.no_configs2:
@@ -592,7 +592,7 @@ def main():
                 im.close()
             del d2, k2, pk2
 
-        # ---- BASELINE configs[3]: exhaustive matching of V views, sharded over the ranks (strong scaling)
+        # ---- the exhaustive configuration: all pairs of V views, sharded over the ranks (strong scaling)
         stage[0] = "allpairs"
         if not args.no_allpairs:
             from sfm_amd import allpairs, synth

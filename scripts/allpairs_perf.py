@@ -1,4 +1,4 @@
-"""Exhaustive matching of V synthetic views (the shape of BASELINE configs[3]:
+"""Exhaustive matching of V synthetic views (the shape of the exhaustive benchmark configuration:
 64 views x 20k descriptors = 2016 pairs) through sfm_amd.allpairs: prepare where
 the images live, all-gather the packed blocks (when launched under torchrun with
 several ranks), deal the pairs, match, all-reduce the count matrices.

@@ -25,7 +25,7 @@ def _oracle_pair(oracle, dq, dt, kq, kt, K, ratio, model, **kw):
 
 
 def test_bench_configuration_full_size_against_oracle(gpu_ctx, oracle):
-    """BASELINE configs[1] as bench.py runs it: pairs of 8192 x 8192 float32
+    """The headline benchmark configuration as bench.py runs it: pairs of 8192 x 8192 float32
     descriptors, ratio 0.7, fundamental RANSAC with 2048 hypotheses (fixed count),
     two pairs of the bench batch through sfm_gpu_match_pairs.  Survivor counts,
     inlier counts and every selected cv::DMatch record (distance bits included)
@@ -62,7 +62,7 @@ def test_randomised_parity_slice(gpu_ctx):
 @pytest.mark.parametrize("own_stream", [True, False])
 def test_exhaustive_matcher_20000_descriptors_cuda_inputs(gpu_ctx, oracle, own_stream):
     """sfm_amd.allpairs with the GPU backend on 6 views x 20 000 descriptors (the
-    per-view size of BASELINE configs[3]) whose descriptors are CUDA tensors
+    per-view size of the exhaustive benchmark configuration) whose descriptors are CUDA tensors
     produced by asynchronous torch work right before the call, once with the
     library on a stream of its own and once on torch's stream.  Three of the 15
     pairs are checked against the oracle pipeline."""
