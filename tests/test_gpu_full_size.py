@@ -90,3 +90,36 @@ def test_exhaustive_matcher_20000_descriptors_cuda_inputs(gpu_ctx, oracle, own_s
         assert good[i, j] == og and inl[i, j] == len(osel), (i, j, good[i, j], og, inl[i, j], len(osel))
     assert inl[0, 1] > 1000 and good[j, i] == 0
     ctx.close()
+
+
+def test_exhaustive_matcher_many_small_views(gpu_ctx, oracle):
+    """The shape of the largest exhaustive configuration scaled down in rows, not
+    in structure: 150 views, all 11 175 pairs, many launch groups of 256 pairs.
+    The count matrices equal pair-by-pair library calls on a sample and the
+    oracle pipeline on a few pairs; neighbouring views share the most inliers."""
+    V, n = 150, 320
+    descs, kps, _ = synth.image_sequence(V, n, 515, shared=0.6)
+    be = allpairs.GpuBackend(gpu_ctx, K=synth.REF_K, model=matcher.MODEL_ESSENTIAL, mode=matcher.RANSAC_ADAPTIVE,
+                             prob=0.99, threshold=1.0, max_iters=300)
+    local = [(d, k) for d, k in zip(descs, kps)]
+    pairs, good, inl = allpairs.match_all_pairs(local, V, be, mode="all")
+    assert len(pairs) == V * (V - 1) // 2 and good.shape == (V, V)
+    assert (np.tril(good) == 0).all() and (np.tril(inl) == 0).all()
+    images = [matcher.Image(gpu_ctx, d, k) for d, k in zip(descs, kps)]
+    rng = np.random.default_rng(3)
+    sample = [(0, 1), (0, V - 1), (V - 2, V - 1)] + [tuple(sorted(rng.choice(V, 2, replace=False))) for _ in range(40)]
+    for (i, j) in sample:
+        g1, i1 = matcher.match_pairs(gpu_ctx, images, np.array([[i, j]], np.int32), synth.REF_K, prob=0.99,
+                                     threshold=1.0, max_iters=300)
+        assert good[i, j] == g1[0] and inl[i, j] == i1[0], (i, j)
+    for (i, j) in sample[:4]:
+        og, osel = _oracle_pair(oracle, descs[i], descs[j], kps[i], kps[j], synth.REF_K, 0.7,
+                                oracle.MODEL_ESSENTIAL, prob=0.99, threshold=1.0, max_iters=300)
+        assert good[i, j] == og and inl[i, j] == len(osel), (i, j)
+    # the first views look at the scene from nearby places: every neighbouring pair finds a geometry
+    adj = np.array([inl[i, i + 1] for i in range(12)])
+    assert adj.min() > 20
+    order, parent = allpairs.spanning_order(inl)
+    assert sorted(order.tolist()) == list(range(V))
+    for im in images:
+        im.close()
