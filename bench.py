@@ -8,7 +8,14 @@ kNN(k=2) -> ratio test (0.7) -> fundamental-matrix
 RANSAC with 2048 hypotheses (fixed count) -> inlier selection.  One step
 processes a batch of independent pairs (--pairs-per-step, default 64) whose
 float32 descriptors and keypoints are already resident in HBM; the conversion
-to the int8 layout is inside the timed region.  With N > 1 every rank runs its
+to the int8 layout is inside the timed region, and so is the path's product:
+every pair's inlier DMatch records (the selectMatches of main.cpp:225-231) are
+left in device memory (`with_records_to_host` in the line is the same loop with
+those records also copied into pinned host memory behind each batch).
+Consecutive steps work on different batches (--wrong-fracs: three input sets
+whose share of geometrically wrong matches differs), so nothing the library
+remembers from an earlier step describes the step it is sizing.
+With N > 1 every rank runs its
 own batch (pairs are independent units: weak scaling, no data-path collective);
 ranks synchronise with a barrier on both sides of the timed region and the
 slowest rank's time is used.
@@ -64,7 +71,8 @@ def cpu_baseline(descs, kps, n_hyp, threads, n_pairs):
     n_good = n_inl = 0
     for p in range(n_pairs):
         t0 = time.perf_counter()
-        m, c = po.knn_match(descs[2 * p], descs[2 * p + 1], 2, nthreads=threads)
+        # byte rows + int32 sums: same records as the float32 restatement (tests/test_oracle_kat.py)
+        m, c = po.knn_match(descs[2 * p], descs[2 * p + 1], 2, nthreads=threads, u8path=True)
         keep = po.ratio_test(m, c, 0.7)
         good = m[keep, 0]
         p1 = kps[2 * p][good["queryIdx"]].astype(np.float64)
@@ -94,8 +102,10 @@ def host_threads():
 
 def spawn_ranks(n):
     """Starts n fresh rank processes of this script (nothing in this process has
-    touched a GPU), waits for them and returns the largest exit code.  Rank 0
-    inherits stdout, so its JSON line is this command's output."""
+    touched a GPU) and returns their exit code: 0 when all end with 0; when one
+    fails, the others are terminated at once (they would otherwise wait for it in
+    a rendezvous or a collective until some outer time limit) and its code is
+    returned.  Rank 0 inherits stdout, so its JSON line is this command's output."""
     import torch
     backend = os.environ.get("SFM_BENCH_BACKEND", "nccl")
     if backend == "nccl" and not os.environ.get("SFM_BENCH_DRYRUN"):
@@ -110,12 +120,36 @@ def spawn_ranks(n):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port))
+        # The hosts this runs on share GPU memory between processes through dmabuf
+        # only; with the legacy IPC mode RCCL's set-up fails in hipIpcGetMemHandle
+        # ("invalid argument").  The machine images export this already: keep it
+        # for the ranks whatever the caller's environment was.
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = abs(code) or 1
+                print("bench.py: rank %d exited with %d; stopping the other ranks" % (procs.index(p), code),
+                      file=sys.stderr, flush=True)
+                break
+    for p in live:   # only non-empty after a failure
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
     return rc
 
 
@@ -134,7 +168,18 @@ def main():
     ap.add_argument("--hyps", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wrong-frac", type=float, default=0.07,
-                    help="share of descriptor matches that are geometrically wrong (reference log: 4-11 %%)")
+                    help="share of descriptor matches that are geometrically wrong in the one-pair block "
+                         "(reference log: 4-11 %%)")
+    ap.add_argument("--wrong-fracs", type=str, default="0.07,0.25,0.12",
+                    help="one input set per value (different pairs, this share of geometrically wrong matches); "
+                         "consecutive steps rotate over the sets, so with two steps in flight no step is sized "
+                         "from a step on its own data")
+    ap.add_argument("--records", type=int, default=1, choices=[0, 1],
+                    help="1: every step leaves each pair's inlier DMatch records in device memory (what match() "
+                         "returns); 0: counts only (the match-count matrix use)")
+    ap.add_argument("--deadline", type=int, default=1500,
+                    help="seconds after which a rank that is still running gives up with exit code 3 (a rendezvous "
+                         "or collective that never completes must not outlive the caller's patience)")
     ap.add_argument("--no-microkernel", action="store_true", help="skip the MFMA-only ceiling launches")
     ap.add_argument("--knn-variant", type=int, default=-1, help="debug: force the sweep kernel shape")
     ap.add_argument("--score-filter", type=int, default=1, help="debug: 0 = double precision only")
@@ -163,19 +208,55 @@ def main():
         # one process per GPU: start the ranks before anything here touches a GPU
         sys.exit(spawn_ranks(args.gpus))
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+
+    # One line per run, whoever prints it (the main thread or a watchdog).
+    out = {}
+    out_lock = threading.Lock()
+    printed = [False]
+    stage = ["start"]
+
+    def print_line_once(extra=None):
+        with out_lock:
+            if printed[0] or rank != 0 or not out:
+                return
+            printed[0] = True
+            line = dict(out)
+            if extra:
+                line.update(extra)
+            print(json.dumps(line), flush=True)
+
+    # Running from before the rendezvous to the end: a rank whose peers never
+    # arrive, or a collective that never completes, ends here with a non-zero
+    # code (rank 0 first prints whatever part of the line it has).
+    def out_of_time():
+        print("bench.py rank %d: deadline of %d s passed in: %s" % (rank, args.deadline, stage[0]),
+              file=sys.stderr, flush=True)
+        print_line_once({"incomplete": "deadline of %d s passed in: %s" % (args.deadline, stage[0])})
+        os._exit(3)
+
+    deadline = threading.Timer(args.deadline, out_of_time)
+    deadline.daemon = True
+    deadline.start()
+
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    pg_timeout = datetime.timedelta(seconds=max(60, min(args.deadline, 600)))
     if os.environ.get("SFM_BENCH_DRYRUN"):
         # control flow only (no GPU work): rendezvous, barrier, reduction, one line
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo")
+            stage[0] = "rendezvous"
+            if os.environ.get("SFM_BENCH_TEST_EXIT_RANK") == str(rank):
+                sys.exit(7)   # rehearsal of a rank that dies before the rendezvous
+            dist.init_process_group("gloo", timeout=pg_timeout)
             t = torch.tensor([float(rank + 1)], dtype=torch.float64)
             dist.barrier()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -190,6 +271,7 @@ def main():
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
+        deadline.cancel()
         return
     from sfm_amd import matcher
     # SFM_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with
@@ -200,26 +282,46 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        stage[0] = "rendezvous"
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
+    # how many ranks the collective library itself reaches: a sum of ones
+    saw_ranks = 1
+    if world > 1:
+        stage[0] = "first all-reduce"
+        ones = torch.ones(1, dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        saw_ranks = int(ones.item())
+    stage[0] = "set-up"
 
     B, n, nh = args.pairs_per_step, args.n_desc, args.hyps
-    descs, kps = make_pairs(B, n, 1000 + 100000 * rank, args.wrong_frac)
+    fracs = [float(x) for x in args.wrong_fracs.split(",") if x.strip()]
     row_bytes = 128 * (1 if args.desc_u8 else 4)  # densely packed rows
     desc_dtype = matcher.DESC_U8 if args.desc_u8 else matcher.DESC_F32
     pairs = np.array([[2 * p, 2 * p + 1] for p in range(B)], np.int32)
     stream = torch.cuda.Stream()
-    with torch.cuda.stream(stream):
-        host_desc = np.stack(descs)
-        if args.desc_u8:
-            host_desc = host_desc.astype(np.uint8)
-        d_desc = torch.from_numpy(host_desc).cuda()                # [2B, n, 128] float32 (or uint8)
-        d_kp = torch.from_numpy(np.stack(kps)).cuda()              # [2B, n, 2] float32
-    stream.synchronize()
-    desc_ptrs = [d_desc[i].data_ptr() for i in range(2 * B)]
-    kp_ptrs = [d_kp[i].data_ptr() for i in range(2 * B)]
+    # One input set per entry of --wrong-fracs: different pairs (other seeds) with
+    # that share of geometrically wrong matches.  Set 0 is also the CPU leg's.
+    inputs = []
+    descs = kps = None
+    for si, wf in enumerate(fracs):
+        d_s, k_s = make_pairs(B, n, 1000 + 100000 * rank + 7000 * si, wf)
+        if si == 0:
+            descs, kps = d_s, k_s
+        with torch.cuda.stream(stream):
+            host_desc = np.stack(d_s)
+            if args.desc_u8:
+                host_desc = host_desc.astype(np.uint8)
+            d_desc = torch.from_numpy(host_desc).cuda()                # [2B, n, 128] float32 (or uint8)
+            d_kp = torch.from_numpy(np.stack(k_s)).cuda()              # [2B, n, 2] float32
+        stream.synchronize()
+        inputs.append(dict(desc=d_desc, kp=d_kp, wrong_frac=wf,
+                           desc_ptrs=[d_desc[i].data_ptr() for i in range(2 * B)],
+                           kp_ptrs=[d_kp[i].data_ptr() for i in range(2 * B)]))
+        del host_desc, d_s, k_s
+    n_in = len(inputs)
     blk = matcher.image_packed_bytes(n)
 
     class Lane:
@@ -244,7 +346,15 @@ def main():
             if args.knn_variant >= 0:
                 self.ctx._L.sfm_gpu_debug_set_knn_variant(self.ctx.handle, args.knn_variant)
             self.packed, self.images, self.prep, self.batch, self.ready = [], [], [], [], []
-            for _ in range(self.n_sets):
+            self.rec_dev, self.rec_host, self.batch_host = [], [], []
+            kw = dict(ratio=0.7, model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED, prob=0.99,
+                      threshold=3.0, n_hyp=nh)
+            for _ in range(2):   # two batches may be in flight: two sets of output buffers
+                with torch.cuda.stream(st):
+                    # each pair's selectMatches: B x n cv::DMatch records (16 bytes each)
+                    self.rec_dev.append(torch.zeros((B, n, 4), dtype=torch.int32, device="cuda"))
+                self.rec_host.append(torch.zeros((B, n, 4), dtype=torch.int32).pin_memory())
+            for si in range(self.n_sets):
                 with torch.cuda.stream(st):
                     d_packed = torch.empty((2 * B, blk), dtype=torch.uint8, device="cuda")
                 st.synchronize()
@@ -252,42 +362,53 @@ def main():
                 images = [matcher.WrappedImage(self.ctx, packed_ptrs[i], n) for i in range(2 * B)]
                 self.packed.append(d_packed)
                 self.images.append(images)
-                # argument arrays of the calls are built once (a C++ host holds them anyway)
-                self.prep.append(matcher.PrepareBatch(self.ctx_prep, desc_ptrs, [n] * (2 * B), row_bytes, desc_dtype,
-                                                      kp_ptrs, packed_ptrs))
-                self.batch.append(matcher.PairBatch(self.ctx, images, pairs, None, ratio=0.7,
-                                                    model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED,
-                                                    prob=0.99, threshold=3.0, n_hyp=nh))
+                # argument arrays of the calls are built once (a C++ host holds them anyway):
+                # one conversion per (input set, packed set), one batch per (packed set, output set)
+                self.prep.append([matcher.PrepareBatch(self.ctx_prep, inp["desc_ptrs"], [n] * (2 * B), row_bytes,
+                                                       desc_dtype, inp["kp_ptrs"], packed_ptrs) for inp in inputs])
+                if args.records:
+                    self.batch.append([matcher.PairBatch(self.ctx, images, pairs, None, records_dev=r.data_ptr(),
+                                                         match_capacity=n, **kw) for r in self.rec_dev])
+                else:
+                    self.batch.append([matcher.PairBatch(self.ctx, images, pairs, None, **kw)] * 2)
+                self.batch_host.append([matcher.PairBatch(self.ctx, images, pairs, None, records_dev=r.data_ptr(),
+                                                          match_capacity=n, records_host=h.data_ptr(), **kw)
+                                        for r, h in zip(self.rec_dev, self.rec_host)])
                 self.ready.append(torch.cuda.Event())
             self.k = 0
             self.pending = []
 
-        def begin_step(self):
-            s = self.k % self.n_sets
+        def begin_step(self, to_host=False):
+            s = self.k % self.n_sets      # packed images this step converts into
+            i = self.k % n_in             # input set of this step
+            o = self.k % 2                # output buffers of this step
             self.k += 1
             if args.prep_stream:
                 matcher.stream_wait_front(self.ctx_prep, self.ctx)   # beside the previous step's RANSAC, not its sweep
-                self.prep[s].run()
+                self.prep[s][i].run()
                 self.ready[s].record(self.side)
                 self.stream.wait_event(self.ready[s])
             else:
-                self.prep[s].run()
-            self.batch[s].begin()
-            self.pending.append(s)
+                self.prep[s][i].run()
+            b = (self.batch_host if to_host else self.batch)[s][o]
+            b.begin()
+            self.pending.append((b, i, o, self.k))
 
         def end_step(self):
-            return self.batch[self.pending.pop(0)].end()
+            b, i, o, k = self.pending.pop(0)
+            g, c = b.end()
+            return g, c, i, o, k
 
     lanes = [Lane(stream if i == 0 else torch.cuda.Stream()) for i in range(args.streams)]
-    ctx, images, prep = lanes[0].ctx, lanes[0].images[0], lanes[0].prep[0]
+    ctx, images = lanes[0].ctx, lanes[0].images[0]
     for lane in lanes:
         if args.score_filter != 1:
             lane.ctx.check(lane.ctx._L.sfm_gpu_debug_set_score_filter(lane.ctx.handle, args.score_filter))
         if args.score_prune != 1:
             lane.ctx.check(lane.ctx._L.sfm_gpu_debug_set_score_prune(lane.ctx.handle, args.score_prune))
 
-    def step():
-        prep.run()
+    def step(i):
+        lanes[0].prep[0][i % n_in].run()
         lanes[0].ctx_prep.synchronize()
         return matcher.match_pairs(ctx, images, pairs, None, ratio=0.7,
                                    model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED,
@@ -297,20 +418,26 @@ def main():
     # (conversion + matching) is enqueued before the host collects the counts of
     # step k, so the GPU does not idle through the host's round trip.  Every
     # step still runs start to finish, in order, on one stream.
-    def run_steps(k, lanes=lanes):
-        res, pending = None, []
+    last = {}   # input set -> (n_good, n_inliers, output set) of its most recent step
+
+    def run_steps(k, lanes=lanes, to_host=False):
+        pending = []
+
+        def collect():
+            g, c, i, o, k = pending.pop(0).end_step()
+            last[i] = (g, c, o, k)
+
         for i in range(k):
             lane = lanes[i % len(lanes)]
-            lane.begin_step()
+            lane.begin_step(to_host)
             pending.append(lane)
             if len(pending) == args.in_flight * len(lanes):
-                res = pending.pop(0).end_step()
+                collect()
         while pending:
-            res = pending.pop(0).end_step()
-        return res
+            collect()
 
     if args.warmup:
-        n_good, n_inl = run_steps(args.warmup)
+        run_steps(args.warmup)
     for lane in lanes:
         matcher.check_inputs(lane.ctx_prep)
 
@@ -325,10 +452,29 @@ def main():
         lane.ctx.profile_enable(True)
         lane.ctx.profile_reset()
     fence()
+    stage[0] = "timed region"
     t0 = time.perf_counter()
-    n_good, n_inl = run_steps(args.steps)
+    run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    stage[0] = "after the timed region"
+    per_set = {i: (float(np.mean(v[0])), float(np.mean(v[1]))) for i, v in sorted(last.items())}
+    n_good = np.concatenate([last[i][0] for i in sorted(last)])
+    n_inl = np.concatenate([last[i][1] for i in sorted(last)])
+    n_inl_set0 = last[0][1] if 0 in last else n_inl
+    # the records of the last step on every input set, as the timed loop left them:
+    # per pair n_inliers records, query rows ascending as match() emits them
+    records_ok = None
+    if args.records and args.streams == 1:
+        records_ok = True
+        torch.cuda.synchronize()
+        for i, (g, c, o, k) in last.items():
+            if k <= lanes[0].k - 2:
+                continue   # that step's output buffers have been reused since
+            rec = lanes[0].rec_dev[o].cpu().numpy()
+            for p_ in range(B):
+                q = rec[p_, :c[p_], 0]
+                records_ok = records_ok and bool((np.diff(q) > 0).all()) and bool((rec[p_, :c[p_], 2] == 0).all())
     knn_ms, knn_cnt = 0.0, 0
     for lane in lanes:
         ms, cnt = lane.ctx.profile_query("knn2_mfma")
@@ -344,8 +490,8 @@ def main():
         pctx.profile_select(None)
         pctx.profile_enable(True)
         pctx.profile_reset()
-    for _ in range(2):
-        step()
+    for it in range(2):
+        step(it)
     ctx.synchronize()
     kern = {}
     for name in ("prep_rows", "knn2_mfma", "knn_finalize", "knn_redo", "ratio_compact", "ransac_prep",
@@ -384,6 +530,34 @@ def main():
                  "what": "this rank, steps alternating over two unordered streams (bench.py --streams 2); "
                          "kernels of different steps overlap, so per-kernel durations are not the kernels' own"}
 
+    # The same loop with each batch's records also copied to pinned host memory
+    # behind the batch (a kernel on a side stream writes exactly the records that
+    # exist): what a host that consumes selectMatches on the CPU, as the
+    # reference's later stages do, would see.
+    to_host = None
+    if args.records and args.streams == 1:
+        stage[0] = "records to host"
+        run_steps(4, to_host=True)
+        torch.cuda.synchronize()
+        k3 = max(10, min(args.steps, 50))
+        t1 = time.perf_counter()
+        run_steps(k3, to_host=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        ok = True
+        for i, (g, c, o, k) in last.items():
+            if k <= lanes[0].k - 2:
+                continue
+            h = lanes[0].rec_host[o].numpy()
+            d = lanes[0].rec_dev[o].cpu().numpy()
+            for p_ in range(B):
+                ok = ok and bool((h[p_, :c[p_]] == d[p_, :c[p_]]).all())
+        to_host = {"pairs_per_s": round(B * k3 / dt, 1), "ms_per_step": round(dt / k3 * 1e3, 3), "steps": k3,
+                   "record_bytes_per_step": int(16 * sum(int(v[1].sum()) for v in last.values()) / max(len(last), 1)),
+                   "host_copy_equals_device_records": ok,
+                   "what": "this rank, after the timed region: the timed loop with every pair's inlier records "
+                           "also written to pinned host memory behind its batch, on a side stream"}
+
     # ceiling on this box: the same sweep with its MFMAs and LDS fragment reads
     # only (no digest, no DMA, no barrier; results are garbage and unused).  That
     # kernel exists in the timing build of the library only, loaded here, after
@@ -419,7 +593,6 @@ def main():
         elapsed = float(t.item())
     joined = dist.get_world_size() if world > 1 else 1
 
-    out = {}
     if rank == 0:
         total_pairs = B * args.steps * world
         value = total_pairs / elapsed
@@ -440,7 +613,7 @@ def main():
                     pipe_busy = pmc.get("mfma_pipe_busy_frac")
             except Exception:
                 traffic = None
-        out = {
+        out.update({
             "metric": "matched image pairs/sec (8k x 8k SIFT, k=2+RANSAC)",
             "value": round(value, 2),
             "unit": "pairs/s",
@@ -462,6 +635,14 @@ def main():
                 "steps_in_flight": args.in_flight * args.streams,
                 "streams": args.streams,
                 "conversion_on_side_stream": bool(args.prep_stream),
+                "output_per_pair": "inlier DMatch records in device memory (selectMatches of main.cpp:225-231) + "
+                                   "(n_good, n_inliers) on the host" if args.records else "(n_good, n_inliers) only",
+                "records_checked": records_ok,
+                "input_sets": [{"wrong_frac": inputs[i]["wrong_frac"], "n_good_mean": per_set[i][0],
+                                "n_inliers_mean": per_set[i][1]} for i in sorted(per_set)],
+                "input_rotation": "step k works on input set k mod %d with %d steps in flight: the sizes the library "
+                                  "remembers when it plans a step come from a step on another set" %
+                                  (n_in, args.in_flight * args.streams),
                 "n_good_mean": float(np.mean(n_good)),
                 "n_inliers_mean": float(np.mean(n_inl)),
             },
@@ -470,8 +651,8 @@ def main():
                 "bound": "mfma",
                 "achieved": round(achieved, 1),
                 "peak": INT8_DENSE_PEAK_TOPS,
-                "unit": "TFLOP/s",
-                "unit_note": "int8 multiply-add counted as 2 ops (TOP/s); peak = dense int8 MFMA",
+                "unit": "TOP/s",
+                "unit_note": "int8 multiply-add counted as 2 ops; peak = dense int8 MFMA",
                 "frac": round(achieved / INT8_DENSE_PEAK_TOPS, 4),
                 "traffic": traffic,
                 "mfma_pipe_busy": {
@@ -489,9 +670,12 @@ def main():
                                           / INT8_DENSE_PEAK_TOPS, 4) if ceil_cnt else None,
                 },
             },
+            "with_records_to_host": to_host,
+            "rccl_saw_ranks": saw_ranks if world > 1 and backend == "nccl" else None,
+            "collective_saw_ranks": saw_ranks,
             "kernels_outside_timed_region": kern,
             "two_unordered_streams_outside_timed_region": probe,
-        }
+        })
         sc = kern.get("ransac_score")
         if sc:
             # RANSAC scoring, second kernel of the step: every candidate model against every
@@ -517,18 +701,17 @@ def main():
                 "note": "the equivalent rate exceeds the FP64 peak because the exact staged bound scores most "
                         "models on a fraction of the points; counters for this kernel: profiles/",
             }
-    # The further blocks (outside the timed region) run under a deadline: if one of
-    # them hangs or fails on any rank -- a collective that never completes, a rank
-    # that ran out of memory -- every rank leaves when the deadline passes and rank 0
-    # still prints the line it has, so the headline measurement is never lost to an
-    # auxiliary block.
+    # The further blocks (outside the timed region) run under a deadline of their
+    # own: if one of them hangs on any rank -- a collective that never completes, a
+    # device that stopped answering -- every rank leaves when it passes; rank 0 first
+    # prints the line it has, so the headline measurement is not lost, and the exit
+    # code (3) says that the run did not finish.
     def give_up():
-        if rank == 0:
-            out["extras_incomplete"] = "deadline of %d s passed in: %s" % (args.extras_deadline, stage[0])
-            print(json.dumps(out), flush=True)
-        os._exit(0)
+        print("bench.py rank %d: the blocks after the timed region did not finish in %d s (in: %s)" %
+              (rank, args.extras_deadline, stage[0]), file=sys.stderr, flush=True)
+        print_line_once({"extras_incomplete": "deadline of %d s passed in: %s" % (args.extras_deadline, stage[0])})
+        os._exit(3)
 
-    stage = ["start"]
     watchdog = threading.Timer(args.extras_deadline, give_up)
     watchdog.daemon = True
     watchdog.start()
@@ -635,14 +818,17 @@ def main():
             }
             del local
 
-    except Exception as e:  # noqa: BLE001 -- reported in the line; peers waiting in a collective meet the deadline
+    except Exception as e:  # noqa: BLE001 -- reported in the line and on stderr; the headline above stands
+        print("bench.py rank %d: %s in %s: %s" % (rank, type(e).__name__, stage[0], e), file=sys.stderr, flush=True)
         if rank == 0:
-            out["extras_error"] = "%s in %s: %s" % (type(e).__name__, stage[0], e)
+            with out_lock:
+                out["extras_error"] = "%s in %s: %s" % (type(e).__name__, stage[0], e)
     if rank == 0:
-        if configs2:
-            out["configs2"] = configs2
-        if allp:
-            out["allpairs"] = allp
+        with out_lock:
+            if configs2:
+                out["configs2"] = configs2
+            if allp:
+                out["allpairs"] = allp
     if world == 1:
         watchdog.cancel()
     if rank == 0:
@@ -655,18 +841,18 @@ def main():
                 "cores": threads,
                 "kind": "port",
                 "host_cpus_visible": os.cpu_count(),
-                "sample": "%d full pairs of the batch (%dx%d kNN threaded over query rows + ratio + F-RANSAC %d hyps "
+                "sample": "%d full pairs of the batch (%dx%d kNN on bytes with int32 sums, threaded over query rows + ratio + F-RANSAC %d hyps "
                           "threaded over hypotheses, %d threads = this process's CPU share): %.2f s kNN, %.2f s "
                           "RANSAC; inliers/pair %.1f (GPU: %.1f)" %
                           (cb["n_pairs"], n, n, nh, threads, cb["knn_seconds"], cb["ransac_seconds"],
-                           cb["n_inliers"], float(np.mean(n_inl[:cb["n_pairs"]]))),
+                           cb["n_inliers"], float(np.mean(n_inl_set0[:cb["n_pairs"]]))),
             }
     if world > 1:
         stage[0] = "final barrier"
         dist.barrier()
     watchdog.cancel()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    deadline.cancel()
+    print_line_once()
     if world > 1:
         dist.destroy_process_group()
     for im in images:

@@ -410,10 +410,28 @@ int sfm_gpu_match_pairs_pose(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int
  *   sfm_gpu_match_pairs_end    waits for the OLDEST batch in flight and returns
  *                     its counts (capacity = room in both arrays, >= that
  *                     batch's n_pairs).
- * Counts only: a caller that needs the inlier records uses sfm_gpu_match_pairs.
+ * sfm_gpu_match_pairs_begin leaves counts only (what the match-count matrix of
+ * exhaustive matching needs); sfm_gpu_match_pairs_begin_records also leaves what
+ * match() itself returns per pair, the selectMatches of main.cpp:225-231, 267:
+ *
+ *   inlier_matches_dev   caller-owned DEVICE memory, n_pairs * match_capacity
+ *                     records; pair p's selectMatches occupy
+ *                     [p*match_capacity, +n_inliers[p]), complete once the matching
+ *                     _end has returned (or for any work queued on the context's
+ *                     stream behind the _begin).  Must stay untouched until then.
+ *   match_capacity    records reserved per pair, >= the largest query image
+ *   inlier_matches_host  optional PINNED host memory of the same shape
+ *                     (hipHostMalloc / hipHostRegister; SFM_GPU_ERR_ARG otherwise):
+ *                     behind the batch, on a stream of its own so that the next
+ *                     batch is not held up, a kernel writes exactly the records
+ *                     that exist into it; valid once the matching _end has returned.
  */
 int sfm_gpu_match_pairs_begin(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images,
                               const int32_t* pairs, int n_pairs, const sfm_gpu_match_params* params);
+int sfm_gpu_match_pairs_begin_records(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images,
+                                      const int32_t* pairs, int n_pairs, const sfm_gpu_match_params* params,
+                                      sfm_gpu_dmatch* inlier_matches_dev, int match_capacity,
+                                      sfm_gpu_dmatch* inlier_matches_host);
 int sfm_gpu_match_pairs_end(sfm_gpu_ctx* ctx, int32_t* n_good, int32_t* n_inliers, int capacity);
 
 /*

@@ -34,6 +34,8 @@ def lib():
         L.oracle_knn_match.argtypes = [vp, c.c_int, c.c_size_t, vp, c.c_int, c.c_size_t,
                                        c.c_int, c.c_int, vp, vp, c.c_int]
         L.oracle_knn_match.restype = c.c_int
+        L.oracle_knn_match_u8path.argtypes = L.oracle_knn_match.argtypes
+        L.oracle_knn_match_u8path.restype = c.c_int
         L.oracle_ratio_test.argtypes = [vp, vp, c.c_int, c.c_int, c.c_double, vp]
         L.oracle_ratio_test.restype = c.c_int
         L.oracle_rng_next.argtypes = [c.c_uint64, c.c_int, vp]
@@ -75,9 +77,10 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
-def knn_match(query, train, k=2, nthreads=1):
+def knn_match(query, train, k=2, nthreads=1, u8path=False):
     """query, train: 2-D float32 arrays (row strides honoured).  Returns
-    (matches[nq,k] structured, counts[nq])."""
+    (matches[nq,k] structured, counts[nq]).  u8path: the integer variant for
+    byte-valued descriptors (same bytes out; the one bench.py times)."""
     query = np.asarray(query)
     train = np.asarray(train)
     assert query.dtype == np.float32 and train.dtype == np.float32
@@ -87,7 +90,8 @@ def knn_match(query, train, k=2, nthreads=1):
     assert query.strides[1] == 4 and (nt == 0 or train.strides[1] == 4)
     out = np.zeros((nq, k), dtype=DMATCH_DTYPE)
     counts = np.zeros(nq, dtype=np.int32)
-    rc = lib().oracle_knn_match(_p(query), nq, query.strides[0] if nq else 4 * dim,
+    fn = lib().oracle_knn_match_u8path if u8path else lib().oracle_knn_match
+    rc = fn(_p(query), nq, query.strides[0] if nq else 4 * dim,
                                 _p(train), nt, train.strides[0] if nt else 4 * dim,
                                 dim, k, _p(out), _p(counts), nthreads)
     assert rc == 0

@@ -35,6 +35,8 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <climits>
+#include <cstdint>
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -94,6 +96,105 @@ void knn_rows(const float* query, int q0, int q1, size_t qstep,
         }
         counts[i] = cnt;
     }
+}
+
+// The same rows for the timing leg of the benchmark: descriptors that hold
+// integers 0..255 (what cv::SIFT emits) are narrowed to bytes once and the sum
+// of squared differences is taken in int32, four query rows against one train
+// row at a time.  The float32 sum knn_rows() forms is exact for such inputs
+// (< 2^24) whatever the order of the additions, so s below converts to the very
+// float knn_rows() passes to sqrt, and the insertion scan is the same scan: a
+// candidate with s >= the integer behind the current K-th distance has
+// sqrtf(s) >= that distance and is rejected there too.  Returns false (nothing
+// written) when an input value is not an integer in 0..255.
+bool knn_rows_u8(const uint8_t* qb, int q0, int q1, const uint8_t* tb, int nt, int dim, int k, oracle_dmatch* out,
+                 int32_t* counts)
+{
+    const int K = std::min(k, nt);
+    constexpr int QB = 4;
+    std::vector<float> dist((size_t)QB * (k > 0 ? k : 1));
+    std::vector<int> nidx((size_t)QB * (k > 0 ? k : 1));
+    std::vector<int32_t> lim(QB);
+    for (int i0 = q0; i0 < q1; i0 += QB) {
+        const int nb = std::min(QB, q1 - i0);
+        const uint8_t* q[QB];
+        for (int b = 0; b < QB; b++) q[b] = qb + (size_t)(i0 + std::min(b, nb - 1)) * dim;
+        for (int b = 0; b < QB; b++) {
+            for (int s = 0; s < k; s++) { dist[(size_t)b * k + s] = FLT_MAX; nidx[(size_t)b * k + s] = -1; }
+            lim[b] = INT32_MAX;   // integer behind dist[K-1]: INT32_MAX while that slot is empty
+        }
+        for (int j = 0; j < nt && K > 0; j++) {
+            const uint8_t* t = tb + (size_t)j * dim;
+            int32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            for (int d = 0; d < dim; d++) {
+                const int tv = t[d];
+                const int d0 = q[0][d] - tv, d1 = q[1][d] - tv, d2 = q[2][d] - tv, d3 = q[3][d] - tv;
+                s0 += d0 * d0;
+                s1 += d1 * d1;
+                s2 += d2 * d2;
+                s3 += d3 * d3;
+            }
+            const int32_t ss[QB] = {s0, s1, s2, s3};
+            for (int b = 0; b < nb; b++) {
+                if (ss[b] >= lim[b]) continue;
+                const float dv = std::sqrt((float)ss[b]);
+                float* db = &dist[(size_t)b * k];
+                int* nb_ = &nidx[(size_t)b * k];
+                if (dv < db[K - 1]) {
+                    int p = K - 2;
+                    for (; p >= 0 && db[p] > dv; p--) {
+                        db[p + 1] = db[p];
+                        nb_[p + 1] = nb_[p];
+                    }
+                    db[p + 1] = dv;
+                    nb_[p + 1] = j;
+                    // smallest integer whose float root reaches the K-th distance: every
+                    // later candidate at or above it is rejected by the float compare too
+                    if (nb_[K - 1] >= 0) {
+                        const float kth = db[K - 1];
+                        int32_t L = (int32_t)((double)kth * (double)kth);
+                        while (L > 0 && std::sqrt((float)(L - 1)) >= kth) --L;
+                        while (std::sqrt((float)L) < kth) ++L;
+                        lim[b] = L;
+                    }
+                }
+            }
+        }
+        for (int b = 0; b < nb; b++) {
+            const int i = i0 + b;
+            int cnt = 0;
+            for (int s = 0; s < k; s++) {
+                oracle_dmatch& m = out[(size_t)i * k + s];
+                m.queryIdx = i;
+                m.imgIdx = 0;
+                if (s < K && nidx[(size_t)b * k + s] >= 0) {
+                    m.trainIdx = nidx[(size_t)b * k + s];
+                    m.distance = dist[(size_t)b * k + s];
+                    cnt++;
+                } else {
+                    m.trainIdx = -1;
+                    m.distance = FLT_MAX;
+                }
+            }
+            counts[i] = cnt;
+        }
+    }
+    return true;
+}
+
+// rows of float32 -> bytes; false when a value is not an integer in 0..255
+bool narrow_rows(const float* src, int n, size_t step, int dim, std::vector<uint8_t>& dst)
+{
+    dst.resize((size_t)std::max(n, 1) * dim);
+    for (int i = 0; i < n; i++) {
+        const float* r = (const float*)((const char*)src + (size_t)i * step);
+        for (int d = 0; d < dim; d++) {
+            const float v = r[d];
+            if (!(v >= 0.f && v <= 255.f) || v != (float)(int)v) return false;
+            dst[(size_t)i * dim + d] = (uint8_t)(int)v;
+        }
+    }
+    return true;
 }
 
 // ------------------------------------------------------------- cv::RNG ----
@@ -948,6 +1049,32 @@ int oracle_knn_match(const float* query, int nq, size_t qstep, const float* trai
         int q0 = t * per, q1 = std::min(nq, q0 + per);
         if (q0 >= q1) break;
         th.emplace_back(knn_rows, query, q0, q1, qstep, train, nt, tstep, dim, k, out, counts);
+    }
+    for (auto& t : th) t.join();
+    return 0;
+}
+
+int oracle_knn_match_u8path(const float* query, int nq, size_t qstep, const float* train, int nt,
+                            size_t tstep, int dim, int k, oracle_dmatch* out, int32_t* counts,
+                            int nthreads)
+{
+    if (nq < 0 || nt < 0 || dim <= 0 || k <= 0) return -1;
+    if (nq == 0) return 0;
+    std::vector<uint8_t> qb, tb;
+    if (!narrow_rows(query, nq, qstep, dim, qb) || !narrow_rows(train, nt, tstep, dim, tb) ||
+        (double)dim * 255.0 * 255.0 >= 16777216.0)
+        return oracle_knn_match(query, nq, qstep, train, nt, tstep, dim, k, out, counts, nthreads);
+    if (nthreads < 1) nthreads = 1;
+    // blocks of four query rows, dealt in contiguous runs
+    const int blocks = (nq + 3) / 4;
+    nthreads = std::min(nthreads, blocks);
+    std::vector<std::thread> th;
+    const int per = (blocks + nthreads - 1) / nthreads * 4;
+    for (int t = 0; t < nthreads; t++) {
+        const int q0 = t * per, q1 = std::min(nq, q0 + per);
+        if (q0 >= q1) break;
+        if (nthreads == 1) knn_rows_u8(qb.data(), q0, q1, tb.data(), nt, dim, k, out, counts);
+        else th.emplace_back(knn_rows_u8, qb.data(), q0, q1, tb.data(), nt, dim, k, out, counts);
     }
     for (auto& t : th) t.join();
     return 0;

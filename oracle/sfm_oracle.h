@@ -46,6 +46,14 @@ int oracle_knn_match(const float* query, int nq, size_t qstep_bytes,
                      int dim, int k, oracle_dmatch* out, int32_t* counts,
                      int nthreads);
 
+/* The same result, byte for byte, by integer arithmetic when every input value
+ * is an integer in 0..255 (cv::SIFT descriptors): the variant bench.py times as
+ * the CPU baseline.  Other inputs fall through to oracle_knn_match. */
+int oracle_knn_match_u8path(const float* query, int nq, size_t qstep_bytes,
+                            const float* train, int nt, size_t tstep_bytes,
+                            int dim, int k, oracle_dmatch* out, int32_t* counts,
+                            int nthreads);
+
 /* Ratio test of main.cpp:189-197: keep row r iff
  * (double)m[r][0].distance < ratio * (double)m[r][1].distance.  Rows with
  * fewer than 2 neighbours are skipped (the reference reads m[r][1]

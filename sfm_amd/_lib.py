@@ -106,6 +106,8 @@ def _load(path):
     L.sfm_gpu_match_pairs_pose.argtypes = [vp, vp, c.c_int, vp, c.c_int, c.POINTER(MatchParams), vp, vp, vp,
                                            c.c_int, c.c_double, vp, vp, vp, vp]
     L.sfm_gpu_match_pairs_begin.argtypes = [vp, vp, c.c_int, vp, c.c_int, c.POINTER(MatchParams)]
+    L.sfm_gpu_match_pairs_begin_records.argtypes = [vp, vp, c.c_int, vp, c.c_int, c.POINTER(MatchParams), vp,
+                                                    c.c_int, vp]
     L.sfm_gpu_match_pairs_end.argtypes = [vp, vp, vp, c.c_int]
     L.sfm_gpu_stream_wait_front.argtypes = [vp, vp]
     L.sfm_gpu_profile_enable.argtypes = [vp, c.c_int]

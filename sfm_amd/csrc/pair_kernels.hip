@@ -137,7 +137,30 @@ __global__ void __launch_bounds__(256) upload_block_kernel(uint4* __restrict__ d
     if (i < n_jobs) *(int32_t*)((char*)redo + (size_t)i * redo_stride) = 0;
 }
 
+// A batch's inlier records on their way to the host: pair p's first
+// counts[2p+1] records go from src + p*stride to dst + p*stride, where dst is
+// pinned host memory the device writes directly.  Only the records that exist
+// travel; the host never has to know the counts before the copy is enqueued.
+// grid = (slices, pairs).
+__global__ void __launch_bounds__(256) records_to_host_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                              size_t stride, const int32_t* __restrict__ counts)
+{
+    const int n = counts[2 * blockIdx.y + 1];
+    const uint4* s = src + (size_t)blockIdx.y * stride;
+    uint4* d = dst + (size_t)blockIdx.y * stride;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = s[i];
+}
+
 }  // namespace
+
+hipError_t launch_records_to_host(hipStream_t s, const sfm_gpu_dmatch* src, sfm_gpu_dmatch* dst_pinned, size_t stride,
+                                  const int32_t* counts, int n_pairs)
+{
+    static_assert(sizeof(sfm_gpu_dmatch) == sizeof(uint4), "one record per 16-byte access");
+    hipLaunchKernelGGL(records_to_host_kernel, dim3(4, n_pairs), dim3(256), 0, s, (const uint4*)src,
+                       (uint4*)dst_pinned, stride, counts);
+    return hipGetLastError();
+}
 
 hipError_t launch_upload_block(hipStream_t s, void* dst, const void* src_pinned, size_t bytes, int32_t* redo,
                                size_t redo_stride, int n_jobs)

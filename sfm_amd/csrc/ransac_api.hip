@@ -478,8 +478,11 @@ struct MpPlan {
     size_t per_pair_ransac = 0, out_b = 0, cnt_b = 0, redo_b = 0, good_b = 0, px_b = 0, inl_b = 0;
 };
 
+// want_inliers: the pairs' inlier records are wanted; own_records: in a buffer of
+// the context (false: the caller brings device memory for them).
 static int mp_plan(sfm_gpu_ctx* ctx, MpPlan& pl, sfm_gpu_image* const* images, int n_images, const int32_t* pairs,
-                   int n_pairs, const sfm_gpu_match_params* params, bool want_inliers, int match_capacity)
+                   int n_pairs, const sfm_gpu_match_params* params, bool want_inliers, int match_capacity,
+                   bool own_records = true)
 {
     for (int p = 0; p < 2 * n_pairs; ++p)
         if (pairs[p] < 0 || pairs[p] >= n_images)
@@ -521,7 +524,7 @@ static int mp_plan(sfm_gpu_ctx* ctx, MpPlan& pl, sfm_gpu_image* const* images, i
     pl.redo_b = align_up(((size_t)pl.nq_max + 1) * 4, 256);
     pl.good_b = align_up((size_t)pl.nq_max * sizeof(sfm_gpu_dmatch), 256);
     pl.px_b = align_up((size_t)pl.nq_max * 16, 256);
-    pl.inl_b = want_inliers ? align_up((size_t)match_capacity * sizeof(sfm_gpu_dmatch), 256) : 0;
+    pl.inl_b = want_inliers && own_records ? align_up((size_t)match_capacity * sizeof(sfm_gpu_dmatch), 256) : 0;
     return SFM_GPU_OK;
 }
 
@@ -545,6 +548,12 @@ static int mp_reserve(sfm_gpu_ctx* ctx, const MpPlan& pl)
     SFM_HIP(ctx, ctx->mp_ngood.reserve(8 * group));
     SFM_HIP(ctx, ctx->rs_counts.reserve((size_t)R_COUNT * 4 * group));
     SFM_HIP(ctx, ctx->rs_models.reserve(pl.per_pair_ransac * group));
+    // the RANSAC workspace is about to be carved anew: what the last sfm_gpu_ransac
+    // call left there (sfm_gpu_ransac_candidates, the test hooks) is gone
+    ctx->last_hyp = -1;
+    ctx->dbg_table = ctx->dbg_counts = ctx->dbg_nmodels = nullptr;
+    ctx->dbg_models = nullptr;
+    ctx->dbg_hyp_cap = 0;
     SFM_HIP(ctx, ctx->jobs.reserve(mp_stage_bytes((int)group)));
     return SFM_GPU_OK;
 }
@@ -552,9 +561,12 @@ static int mp_reserve(sfm_gpu_ctx* ctx, const MpPlan& pl)
 // Enqueues one group of pairs (g0 .. g0+g) on the context's stream; the last
 // kernel leaves the (n_good, n_inliers) words in `res_pinned` (pinned host memory).  In
 // fixed-count mode nothing here waits for the device.
+// records_dev: caller-owned device memory for the inlier records (pair p's at
+// records_dev + p * match_capacity), or null: a buffer of the context when
+// want_inliers, none otherwise.
 static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* images, const int32_t* pairs,
                       int g0, int g, const sfm_gpu_match_params* params, bool want_inliers, int match_capacity,
-                      std::vector<PairDev>& pds, void* res_pinned)
+                      std::vector<PairDev>& pds, void* res_pinned, sfm_gpu_dmatch* records_dev = nullptr)
 {
     hipStream_t s = ctx->stream;
     std::vector<KnnJob> jobs(g);
@@ -592,7 +604,9 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
         pd.kp_q = q.kp;
         pd.kp_t = t.kp;
         pd.good = (sfm_gpu_dmatch*)(ctx->mp_good.as<char>() + (pl.good_b + pl.inl_b) * i);
-        pd.inliers = want_inliers ? (sfm_gpu_dmatch*)((char*)pd.good + pl.good_b) : nullptr;
+        pd.inliers = !want_inliers ? nullptr
+                     : records_dev ? records_dev + (size_t)(g0 + i) * match_capacity
+                                   : (sfm_gpu_dmatch*)((char*)pd.good + pl.good_b);
         pd.px1 = (double*)(ctx->mp_pts.as<char>() + pl.px_b * 2 * i);
         pd.px2 = (double*)(ctx->mp_pts.as<char>() + pl.px_b * 2 * i + pl.px_b);
         pd.n_good = ctx->mp_ngood.as<int32_t>() + 2 * i;
@@ -765,37 +779,84 @@ int sfm_gpu_match_pairs_pose(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int
                             match_capacity, &po);
 }
 
-int sfm_gpu_match_pairs_begin(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images,
-                              const int32_t* pairs, int n_pairs, const sfm_gpu_match_params* params)
+static int match_pairs_begin_impl(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images, const int32_t* pairs,
+                                  int n_pairs, const sfm_gpu_match_params* params, sfm_gpu_dmatch* records_dev,
+                                  int match_capacity, sfm_gpu_dmatch* records_host)
 {
-    if (!ctx) return SFM_GPU_ERR_ARG;
     if (n_pairs < 1 || n_images < 0 || !params || !images || !pairs)
         return ctx->fail(SFM_GPU_ERR_ARG, "null pointer or no pairs");
+    if (records_host && !records_dev)
+        return ctx->fail(SFM_GPU_ERR_ARG, "records on the host need the device buffer they are copied from");
     if (ctx->mp_outstanding >= 2)
         return ctx->fail(SFM_GPU_ERR_CAPACITY, "two batches are already in flight: call sfm_gpu_match_pairs_end first");
     MpPlan pl;
-    int rc = mp_plan(ctx, pl, images, n_images, pairs, n_pairs, params, false, 0);
+    int rc = mp_plan(ctx, pl, images, n_images, pairs, n_pairs, params, records_dev != nullptr, match_capacity, false);
     if (rc) return rc;
     if (pl.group < n_pairs)
         return ctx->fail(SFM_GPU_ERR_CAPACITY, "%d pairs of this size do not fit one batch (%d at most)", n_pairs,
                          pl.group);
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    sfm_gpu_dmatch* host_dev = nullptr;  // the device's address of the caller's pinned buffer
+    if (records_host) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, records_host) != hipSuccess || at.type != hipMemoryTypeHost ||
+            !at.devicePointer) {
+            (void)hipGetLastError();
+            return ctx->fail(SFM_GPU_ERR_ARG, "inlier_matches_host must be pinned host memory (hipHostMalloc / "
+                                              "hipHostRegister): the device writes it directly");
+        }
+        host_dev = (sfm_gpu_dmatch*)at.devicePointer;
+        if (!ctx->rec_stream) SFM_HIP(ctx, hipStreamCreateWithFlags(&ctx->rec_stream, hipStreamNonBlocking));
+    }
     rc = mp_reserve(ctx, pl);
     if (rc) return rc;
     sfm_gpu_ctx::MpSlot& slot = ctx->mp_slot[ctx->mp_next];
     if (!slot.ev) SFM_HIP(ctx, hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
+    if (records_host && !slot.rec_ev) SFM_HIP(ctx, hipEventCreateWithFlags(&slot.rec_ev, hipEventDisableTiming));
     SFM_HIP(ctx, slot.stage.reserve(mp_stage_bytes(n_pairs)));
     SFM_HIP(ctx, slot.res.reserve(8 * (size_t)n_pairs));
     std::vector<PairDev> pds;
     ctx->up_stage = &slot.stage;  // this slot's previous batch has been ended
     ctx->up_used = 0;
-    rc = mp_enqueue(ctx, pl, images, pairs, 0, n_pairs, params, false, 0, pds, slot.res.p);
+    rc = mp_enqueue(ctx, pl, images, pairs, 0, n_pairs, params, records_dev != nullptr, match_capacity, pds,
+                    slot.res.p, records_dev);
     ctx->up_stage = nullptr;
     if (rc) return rc;
     SFM_HIP(ctx, hipEventRecord(slot.ev, ctx->stream));
+    slot.rec_pending = false;
+    if (records_host) {
+        // behind the batch, on a stream of its own: the next batch starts on the
+        // context's stream while these records travel.  The counts are read from
+        // this slot's pinned block, which nothing overwrites before _end.
+        SFM_HIP(ctx, hipStreamWaitEvent(ctx->rec_stream, slot.ev, 0));
+        SFM_HIP(ctx, launch_records_to_host(ctx->rec_stream, records_dev, host_dev, (size_t)match_capacity,
+                                            slot.res.as<int32_t>(), n_pairs));
+        SFM_HIP(ctx, hipEventRecord(slot.rec_ev, ctx->rec_stream));
+        slot.rec_pending = true;
+    }
     slot.n_pairs = n_pairs;
     ctx->mp_next ^= 1;
     ++ctx->mp_outstanding;
     return SFM_GPU_OK;
+}
+
+int sfm_gpu_match_pairs_begin(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images,
+                              const int32_t* pairs, int n_pairs, const sfm_gpu_match_params* params)
+{
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    return match_pairs_begin_impl(ctx, images, n_images, pairs, n_pairs, params, nullptr, 0, nullptr);
+}
+
+int sfm_gpu_match_pairs_begin_records(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images,
+                                      const int32_t* pairs, int n_pairs, const sfm_gpu_match_params* params,
+                                      sfm_gpu_dmatch* inlier_matches_dev, int match_capacity,
+                                      sfm_gpu_dmatch* inlier_matches_host)
+{
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    if (!inlier_matches_dev || match_capacity < 1)
+        return ctx->fail(SFM_GPU_ERR_ARG, "sfm_gpu_match_pairs_begin_records: no device buffer for the records");
+    return match_pairs_begin_impl(ctx, images, n_images, pairs, n_pairs, params, inlier_matches_dev, match_capacity,
+                                  inlier_matches_host);
 }
 
 int sfm_gpu_stream_wait_front(sfm_gpu_ctx* waiter, sfm_gpu_ctx* source)
@@ -818,6 +879,10 @@ int sfm_gpu_match_pairs_end(sfm_gpu_ctx* ctx, int32_t* n_good, int32_t* n_inlier
     if (capacity < slot.n_pairs)
         return ctx->fail(SFM_GPU_ERR_CAPACITY, "the oldest batch has %d pairs, room for %d", slot.n_pairs, capacity);
     SFM_HIP(ctx, hipEventSynchronize(slot.ev));
+    if (slot.rec_pending) {
+        SFM_HIP(ctx, hipEventSynchronize(slot.rec_ev));
+        slot.rec_pending = false;
+    }
     --ctx->mp_outstanding;
     mp_collect(ctx, slot.res.as<int32_t>(), slot.n_pairs, n_good, n_inliers);
     return SFM_GPU_OK;

@@ -147,6 +147,9 @@ hipError_t launch_ratio_compact(hipStream_t s, const PairDev* pairs, int n_pairs
 hipError_t launch_upload_block(hipStream_t s, void* dst, const void* src_pinned, size_t bytes, int32_t* redo,
                                size_t redo_stride, int n_jobs);
 hipError_t launch_inlier_compact(hipStream_t s, const PairDev* pairs, int n_pairs);
+// pair p's first counts[2p+1] records from src + p*stride to dst_pinned + p*stride (device-visible host memory)
+hipError_t launch_records_to_host(hipStream_t s, const sfm_gpu_dmatch* src, sfm_gpu_dmatch* dst_pinned, size_t stride,
+                                  const int32_t* counts, int n_pairs);
 // pairs != null: the kernel also gathers each pair's inlier matches and reports
 // its two counts (what launch_inlier_compact does as a launch of its own)
 hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp,

@@ -171,6 +171,8 @@ struct sfm_gpu_ctx {
     // sfm_gpu_match_pairs_begin / _end: up to two batches in flight
     struct MpSlot {
         hipEvent_t ev = nullptr;
+        hipEvent_t rec_ev = nullptr;  // behind the batch's copy of its records to the host, when it has one
+        bool rec_pending = false;
         sfm::PinnedBuf stage, res;
         int n_pairs = 0;
     };
@@ -178,6 +180,9 @@ struct sfm_gpu_ctx {
     int mp_next = 0;         // slot the next begin takes
     int mp_outstanding = 0;  // begun and not yet ended (the oldest is mp_next - mp_outstanding)
     sfm::PinnedBuf mp_stage_sync, mp_res_sync;
+    // side stream on which a batch's inlier records travel to the host while the
+    // next batch already runs on `stream` (created on first use)
+    hipStream_t rec_stream = nullptr;
     // recorded behind the sweep and the neighbour extraction of every pair batch
     // once another context has asked to wait for it (sfm_gpu_stream_wait_front)
     hipEvent_t front_ev = nullptr;

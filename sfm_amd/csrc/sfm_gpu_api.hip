@@ -298,8 +298,13 @@ void sfm_gpu_destroy(sfm_gpu_ctx* c)
     }
     for (auto& slot : c->mp_slot) {
         if (slot.ev) (void)hipEventDestroy(slot.ev);
+        if (slot.rec_ev) (void)hipEventDestroy(slot.rec_ev);
         slot.stage.release();
         slot.res.release();
+    }
+    if (c->rec_stream) {
+        (void)hipStreamSynchronize(c->rec_stream);
+        (void)hipStreamDestroy(c->rec_stream);
     }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;

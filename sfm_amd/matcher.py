@@ -343,7 +343,11 @@ class PairBatch:
     its (n_good, n_inliers).  At most two batches may be in flight."""
 
     def __init__(self, ctx, images, pairs, K, ratio=0.7, model=MODEL_ESSENTIAL, mode=RANSAC_ADAPTIVE,
-                 prob=0.99, threshold=1.0, max_iters=1000, n_hyp=0):
+                 prob=0.99, threshold=1.0, max_iters=1000, n_hyp=0, records_dev=None, match_capacity=0,
+                 records_host=None):
+        """records_dev: device address of n_pairs * match_capacity cv::DMatch records
+        that receive each pair's selectMatches (main.cpp:225-231, 267); records_host:
+        address of pinned host memory of the same shape, filled behind the batch."""
         self.ctx = ctx
         self._images = list(images)             # keeps the handles alive
         self._pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
@@ -351,9 +355,16 @@ class PairBatch:
         self._arr = (ctypes.c_void_p * len(images))(*[im.handle for im in images])
         self._p = _match_params(K, ratio, model, mode, prob, threshold, max_iters, n_hyp)
         self._args = (ctx.handle, self._arr, len(images), ptr(self._pairs), self.n_pairs, ctypes.byref(self._p))
+        self._records = records_dev is not None
+        if self._records:
+            self._args = self._args + (ctypes.c_void_p(records_dev), int(match_capacity),
+                                       ctypes.c_void_p(records_host) if records_host else None)
 
     def begin(self):
-        self.ctx.check(self.ctx._L.sfm_gpu_match_pairs_begin(*self._args))
+        if self._records:
+            self.ctx.check(self.ctx._L.sfm_gpu_match_pairs_begin_records(*self._args))
+        else:
+            self.ctx.check(self.ctx._L.sfm_gpu_match_pairs_begin(*self._args))
 
     def end(self):
         n_good = np.zeros(self.n_pairs, dtype=np.int32)

@@ -78,3 +78,17 @@ def test_two_gloo_ranks_equal_one_process(tmp_path, mode):
         assert (r["inl"] == one["inl"]).all()
     # the workload is not trivial: overlapping images do match
     assert one["good"].sum() > 0 and one["inl"].sum() > 0
+
+
+@pytest.mark.parametrize("world", [3, 4, 8])
+def test_more_ranks_than_divide_the_images_equal_one_process(tmp_path, world):
+    """Five images over 3, 4 and 8 ranks: uneven ownership, and with 8 ranks three
+    of them own no image at all and still take part in the all-gather, the deal
+    and the all-reduce."""
+    one = run_world(1, str(tmp_path), "all")[0]
+    many = run_world(world, str(tmp_path), "all")
+    assert len(many) == world
+    for r in many:
+        assert (r["pairs"] == one["pairs"]).all()
+        assert (r["good"] == one["good"]).all()
+        assert (r["inl"] == one["inl"]).all()

@@ -385,3 +385,98 @@ def test_conversion_on_a_second_context_ordered_behind_the_front_of_a_batch(gpu_
         for im in lane[2]:
             im.close()
     side.close()
+
+
+@pytest.mark.parametrize("mode", ["fixed", "adaptive"])
+def test_begin_end_leaves_each_pairs_select_matches_on_device_and_host(gpu_ctx, oracle, mode):
+    """The records form of begin/end: what match() returns per pair
+    (main.cpp:225-231, 267) lands in caller-owned device memory and, behind the
+    batch on a side stream, in a pinned host buffer -- bytes equal to the
+    oracle pipeline's selectMatches and to the blocking call's, two batches in
+    flight, the second one smaller and with other images, slots reused."""
+    import torch
+    from sfm_amd import _lib
+    rng = np.random.default_rng(2718)
+    pool = synth.sift_like(2600, 2719)
+    descs, kps, images = [], [], []
+    for v in range(5):
+        n = 1000 + 173 * v
+        d = np.clip(pool[rng.permutation(2600)[:n]] + rng.integers(-4, 5, (n, 128)), 0, 255).astype(np.float32)
+        kp = np.stack([rng.uniform(0, synth.IMG_W, n), rng.uniform(0, synth.IMG_H, n)], 1).astype(np.float32)
+        descs.append(d)
+        kps.append(kp)
+    # geometry for the pairs used below, so that RANSAC has something to find
+    for (a, b, seed) in [(0, 1, 1), (1, 2, 2), (2, 3, 3), (4, 0, 4), (3, 1, 5)]:
+        na, nb = len(descs[a]), len(descs[b])
+        cnt = 500
+        rq, rt = rng.permutation(na)[:cnt], rng.permutation(nb)[:cnt]
+        descs[b][rt] = np.clip(descs[a][rq] + np.rint(rng.normal(0, 5, (cnt, 128))), 0, 255).astype(np.float32)
+        planted = np.full(na, -1, np.int64)
+        planted[rq] = rt
+        kq, kt = synth.keypoints_for_pair(na, nb, planted, 60 + seed, wrong_frac=0.1)
+        kps[a][rq] = kq[rq]
+        kps[b][rt] = kt[rt]
+    images = [matcher.Image(gpu_ctx, d, k) for d, k in zip(descs, kps)]
+    pa = np.array([[0, 1], [1, 2], [2, 3]], np.int32)
+    pb = np.array([[4, 0], [3, 1]], np.int32)
+    if mode == "fixed":
+        K, model = None, matcher.MODEL_FUNDAMENTAL
+        kw = dict(ratio=0.8, model=model, mode=matcher.RANSAC_FIXED, prob=0.99, threshold=3.0, n_hyp=96)
+        okw = dict(prob=0.99, threshold=3.0, fixed_count=96)
+    else:
+        K, model = synth.REF_K, matcher.MODEL_ESSENTIAL
+        kw = dict(ratio=0.8, model=model, prob=0.99, threshold=1.0)
+        okw = dict(prob=0.99, threshold=1.0, max_iters=1000)
+    cap = max(len(d) for d in descs)
+    want = {}
+    for name, pl in (("a", pa), ("b", pb)):
+        g, i, sel = matcher.match_pairs(gpu_ctx, images, pl, K, want_matches=True, **kw)
+        for p, (qi, ti) in enumerate(pl):
+            ng, osel = _oracle_pair(oracle, descs[qi], descs[ti], kps[qi], kps[ti], K, 0.8, model, **okw)
+            assert g[p] == ng and i[p] == len(osel) and sel[p].tobytes() == osel.tobytes()
+        want[name] = (g, i, sel)
+        assert i.sum() > 100
+    dev = {k: torch.full((len(pl), cap, 4), -7, dtype=torch.int32, device="cuda") for k, pl in (("a", pa), ("b", pb))}
+    host = {k: torch.full((len(pl), cap, 4), -9, dtype=torch.int32).pin_memory() for k, pl in (("a", pa), ("b", pb))}
+    torch.cuda.synchronize()
+    ba = matcher.PairBatch(gpu_ctx, images, pa, K, records_dev=dev["a"].data_ptr(), match_capacity=cap,
+                           records_host=host["a"].data_ptr(), **kw)
+    bb = matcher.PairBatch(gpu_ctx, images, pb, K, records_dev=dev["b"].data_ptr(), match_capacity=cap,
+                           records_host=host["b"].data_ptr(), **kw)
+    only_dev = matcher.PairBatch(gpu_ctx, images, pb, K, records_dev=dev["b"].data_ptr(), match_capacity=cap, **kw)
+    for rep in range(3):
+        ba.begin()
+        bb.begin()
+        got = {"a": ba.end(), "b": bb.end()}
+        gpu_ctx.synchronize()
+        for name in ("a", "b"):
+            g, i, sel = want[name]
+            assert (got[name][0] == g).all() and (got[name][1] == i).all()
+            h = host[name].numpy().view(_lib.DMATCH_DTYPE).reshape(len(g), cap)
+            d = dev[name].cpu().numpy().view(_lib.DMATCH_DTYPE).reshape(len(g), cap)
+            for p in range(len(g)):
+                assert h[p, :i[p]].tobytes() == sel[p].tobytes()
+                assert d[p, :i[p]].tobytes() == sel[p].tobytes()
+                assert (host[name][p, i[p]:] == -9).all()        # nothing beyond the records travels
+            host[name].fill_(-9)
+            dev[name].fill_(-7)
+        torch.cuda.synchronize()
+    # device records without a host copy
+    only_dev.begin()
+    g, i = only_dev.end()
+    d = dev["b"].cpu().numpy().view(_lib.DMATCH_DTYPE).reshape(len(pb), cap)
+    for p in range(len(pb)):
+        assert d[p, :i[p]].tobytes() == want["b"][2][p].tobytes()
+    # misuse: pageable host memory, capacity below the largest query image
+    pageable = np.zeros((len(pb), cap), _lib.DMATCH_DTYPE)
+    bad = matcher.PairBatch(gpu_ctx, images, pb, K, records_dev=dev["b"].data_ptr(), match_capacity=cap,
+                            records_host=pageable.ctypes.data, **kw)
+    with pytest.raises(_lib.SfmGpuError) as e:
+        bad.begin()
+    assert e.value.code == _lib.ERR_ARG
+    small = matcher.PairBatch(gpu_ctx, images, pb, K, records_dev=dev["b"].data_ptr(), match_capacity=100, **kw)
+    with pytest.raises(_lib.SfmGpuError) as e:
+        small.begin()
+    assert e.value.code == _lib.ERR_CAPACITY
+    for im in images:
+        im.close()

@@ -421,3 +421,55 @@ def test_rotation_vector_special_angles(oracle):
     a = 0.3
     Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
     assert np.allclose(oracle.rotation_vector(Rz), [0, 0, a])
+
+
+@pytest.mark.parametrize("kind", ["sift", "uniform", "ties", "collisions", "ragged"])
+def test_integer_knn_variant_returns_the_same_bytes(oracle, kind):
+    """The variant the benchmark times as the CPU baseline (bytes + int32 sums,
+    four query rows per pass) against the float32 restatement: every record and
+    count equal, including tie order, distances at and above 2^22 where distinct
+    integers share a float root, and a row count that is no multiple of four."""
+    from sfm_amd import synth
+    rng = np.random.default_rng(99)
+    if kind == "sift":
+        Q, T = synth.sift_like(203, 5), synth.sift_like(517, 6)
+    elif kind == "uniform":
+        Q = rng.integers(0, 256, (131, 128)).astype(np.float32)
+        T = rng.integers(0, 256, (260, 128)).astype(np.float32)
+    elif kind == "ties":
+        Q = (rng.integers(0, 2, (97, 128)) * 50).astype(np.float32)
+        T = (rng.integers(0, 2, (301, 128)) * 50).astype(np.float32)
+        T[40:80] = T[0:40]
+    elif kind == "collisions":
+        # far-apart rows: every distance squared is above 2^22
+        Q = rng.integers(0, 30, (64, 128)).astype(np.float32)
+        T = rng.integers(215, 256, (333, 128)).astype(np.float32)
+    else:
+        Q, T = synth.sift_like(6, 7), synth.sift_like(3, 8)
+    for k in (1, 2):
+        for nt in (len(T), 1, 0):
+            a, ca = oracle.knn_match(Q, T[:nt], k, nthreads=3)
+            b, cb = oracle.knn_match(Q, T[:nt], k, nthreads=3, u8path=True)
+            assert a.tobytes() == b.tobytes() and (ca == cb).all()
+    if kind == "collisions":
+        d2 = ((Q[:, None, :] - T[None, :, :]) ** 2).sum(-1)
+        assert d2.min() >= 2 ** 22
+    # non-byte values fall through to the float path
+    Q2 = Q.copy()
+    Q2[0, 0] = 0.5
+    a, ca = oracle.knn_match(Q2, T, 2)
+    b, cb = oracle.knn_match(Q2, T, 2, u8path=True)
+    assert a.tobytes() == b.tobytes()
+
+
+def test_oracle_runs_clean_under_address_and_undefined_sanitizers():
+    """`make -C oracle asan`: the oracle's sources built with
+    -fsanitize=address,undefined and run through every entry point on small
+    known cases (oracle/selfcheck.cpp)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "--no-print-directory", "asan"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-3000:])
+    assert "oracle selfcheck ok" in p.stdout
