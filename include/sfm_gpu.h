@@ -376,16 +376,19 @@ int sfm_gpu_match_pairs(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_im
 
 /*
  * sfm_gpu_match_pairs followed, for every pair, by what main.cpp:400-420 does
- * with the first pair: recoverPose(E, pointsL, pointsR, K, R, T) on the pair's
- * selectMatches -- here with the essential matrix the pair's own RANSAC found
- * (params->model must be SFM_GPU_MODEL_ESSENTIAL) and without the points ever
- * leaving the GPU: one vote launch per group of pairs.
+ * with the first pair: the points of the pair's selectMatches are gathered
+ * (main.cpp:400-416), findEssentialMat(pointsL, pointsR, K, RANSAC) runs on them
+ * with OpenCV's defaults -- prob 0.999, threshold 1.0, at most 1000 iterations,
+ * the adaptive loop (main.cpp:418) -- and recoverPose(E, pointsL, pointsR, K, R, T)
+ * takes that matrix and lets every selected match vote (main.cpp:420).  The
+ * points never leave the GPU.  params->model must be SFM_GPU_MODEL_ESSENTIAL.
  *
  *   distance_thresh   as in sfm_gpu_recover_pose (OpenCV's default: 50.0)
- *   models_out    out, optional: n_pairs x 9 doubles, each pair's essential matrix
+ *   models_out    out, optional: n_pairs x 9 doubles, the essential matrix of each
+ *                 pair's SECOND RANSAC (the one the pose is decomposed from)
  *   R_out, t_out  out: n_pairs x 9 and n_pairs x 3 doubles
  *   n_pose_good   out, per pair: recoverPose's return value; -1 (and R, t, model
- *                 all zero) for a pair whose RANSAC found no model
+ *                 all zero) for a pair whose first or second RANSAC found no model
  */
 int sfm_gpu_match_pairs_pose(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images,
                              const int32_t* pairs, int n_pairs, const sfm_gpu_match_params* params,

@@ -151,7 +151,32 @@ __global__ void __launch_bounds__(256) records_to_host_kernel(const uint4* __res
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = s[i];
 }
 
+// The points of a pair's selectMatches, as main.cpp:400-416 gathers them for the
+// pose of the first pair: keypoints[.][m.queryIdx].pt and keypoints[.][m.trainIdx].pt
+// widened to double.  grid = (tiles of 256 matches, pairs).
+__global__ void __launch_bounds__(256) gather_inlier_points_kernel(const PairDev* __restrict__ pairs)
+{
+    const PairDev pd = pairs[blockIdx.y];
+    const int n = *pd.n_inliers;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n || !pd.inliers) return;
+    const sfm_gpu_dmatch m = pd.inliers[j];
+    const float2 a = pd.kp_q[m.queryIdx];
+    const float2 b = pd.kp_t[m.trainIdx];
+    pd.px1[2 * j] = (double)a.x;
+    pd.px1[2 * j + 1] = (double)a.y;
+    pd.px2[2 * j] = (double)b.x;
+    pd.px2[2 * j + 1] = (double)b.y;
+}
+
 }  // namespace
+
+hipError_t launch_gather_inlier_points(hipStream_t s, const PairDev* pairs, int n_pairs, int n_query_max)
+{
+    const int tiles = std::max(1, (n_query_max + 255) / 256);
+    hipLaunchKernelGGL(gather_inlier_points_kernel, dim3(tiles, n_pairs), dim3(256), 0, s, pairs);
+    return hipGetLastError();
+}
 
 hipError_t launch_records_to_host(hipStream_t s, const sfm_gpu_dmatch* src, sfm_gpu_dmatch* dst_pinned, size_t stride,
                                   const int32_t* counts, int n_pairs)

@@ -90,9 +90,11 @@ __global__ __launch_bounds__(256) void pose_vote_kernel(const double2* __restric
 // very values pose_vote_kernel computes from the pixels).  A pair whose
 // args[].dist is negative has no model and is skipped.  votes: [pairs][4], zeroed
 // by the caller.
+// every_point != 0: every correspondence of the problem votes, whatever its mask
+// says (recoverPose called without a mask, as at main.cpp:420).
 __global__ __launch_bounds__(256) void pose_vote_pairs_kernel(const RansacProb* __restrict__ probs,
                                                               const PoseVoteArgs* __restrict__ args,
-                                                              int32_t* __restrict__ votes)
+                                                              int32_t* __restrict__ votes, int every_point)
 {
     __shared__ int32_t s_votes[4];
     const RansacProb pb = probs[blockIdx.y];
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void pose_vote_pairs_kernel(const RansacProb* 
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     unsigned f = 0;
-    if (i < n && pb.mask[i]) {
+    if (i < n && (every_point || pb.mask[i])) {
         const double x1 = pb.x1[2 * i], y1 = pb.x1[2 * i + 1], x2 = pb.x2[2 * i], y2 = pb.x2[2 * i + 1];
         const double bb = (x2 * x2 + y2 * y2) + 1.0;
 #pragma unroll
@@ -222,7 +224,7 @@ static int best_candidate(const int32_t* votes)
 // (stream drained): each pair's RANSAC model against that pair's inliers.
 int pose_for_pairs(sfm_gpu_ctx* ctx, const RansacProb* dprobs, int g, const int32_t* n_inliers, const double* K,
                    double distance_thresh, double* models_out, double* R_out, double* t_out, int32_t* n_pose_good,
-                   int nq_max)
+                   int nq_max, bool every_point)
 {
     hipStream_t s = ctx->stream;
     const size_t args_b = sizeof(PoseVoteArgs) * (size_t)g;
@@ -260,7 +262,7 @@ int pose_for_pairs(sfm_gpu_ctx* ctx, const RansacProb* dprobs, int g, const int3
     SFM_HIP(ctx, hipMemsetAsync(dvotes, 0, (size_t)g * 16, s));
     {
         ProfScope ps(ctx, "pose_vote");
-        pose_vote_pairs_kernel<<<dim3((nq_max + 255) / 256 > 0 ? (nq_max + 255) / 256 : 1, g), 256, 0, s>>>(dprobs, dargs, dvotes);
+        pose_vote_pairs_kernel<<<dim3((nq_max + 255) / 256 > 0 ? (nq_max + 255) / 256 : 1, g), 256, 0, s>>>(dprobs, dargs, dvotes, every_point ? 1 : 0);
         SFM_HIP(ctx, hipGetLastError());
     }
     SFM_HIP(ctx, hipMemcpyAsync(hvotes, dvotes, (size_t)g * 16, hipMemcpyDeviceToHost, s));

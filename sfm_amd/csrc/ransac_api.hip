@@ -172,24 +172,10 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, rp.model, 0, nh, gen));
         }
         {
-            // First stage of the scoring: it has to outnumber the outliers for the
-            // bound to drop anything.  Sized from the outliers the previous call on
-            // this context ended with (consecutive pairs of one sequence are alike)
-            // plus 30 %; without history, 1/8 of the points when `cap` is the point
-            // count itself (direct call), 1/16 when it is the query count of a pair,
-            // of which the ratio test leaves less than half.  Only the cost depends
-            // on the guess, never the result.
-            int stage1 = std::max(512, cap / (need_results ? 8 : 16));
-            if (ctx->hint_outliers >= 0.0) stage1 = std::max(512, (int)(1.3 * ctx->hint_outliers) + 1);
-            stage1 = std::min(stage1, std::max(512, cap / 2));
-            // A second cut about a third of the way through the remaining points,
-            // when the previous call says how many points to expect and there are
-            // enough of them left to pay for the extra launches.
-            int mid = 0;
-            const int s1_pts = (stage1 + 127) / 128 * 128;
-            if (ctx->hint_points - s1_pts >= 1024.0) mid = s1_pts + (int)(0.35 * (ctx->hint_points - s1_pts));
+            // staged scoring with an exact bound; the stages are sized per problem
+            // on the device (ransac_plan_kernel), nothing here depends on earlier calls
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh, stage1, mid, ctx->score_filter,
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, 0, nh, true, ctx->score_filter,
                                              ctx->score_prune));
         }
         {
@@ -236,7 +222,7 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         }
         {
             ProfScope ps(ctx, "ransac_score");
-            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, done_rows, b, 0, 0, ctx->score_filter,
+            SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, done_rows, b, false, ctx->score_filter,
                                              ctx->score_prune));
         }
         counts.resize((size_t)n_prob * b * 10);
@@ -423,8 +409,6 @@ int sfm_gpu_ransac(sfm_gpu_ctx* ctx, const double* pts1, const double* pts2, int
     if (iters_used) *iters_used = results[R_ITERS];
     if (results[R_OK]) {
         if (n_inliers) *n_inliers = results[R_NINL];
-        ctx->hint_outliers = n - results[R_NINL];
-        ctx->hint_points = n;
         SFM_HIP(ctx, hipMemcpyAsync(mask, probs[0].mask, n, hipMemcpyDeviceToHost, ctx->stream));
         SFM_HIP(ctx, hipMemcpyAsync(model_out, probs[0].model_out, 72, hipMemcpyDeviceToHost, ctx->stream));
         SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -679,23 +663,12 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
     return SFM_GPU_OK;  // inlier_compact has written the counts into res_pinned
 }
 
-// Copies one group's counts out of `res` and refreshes the sizing hints.
-static void mp_collect(sfm_gpu_ctx* ctx, const int32_t* res, int g, int32_t* n_good, int32_t* n_inliers)
+// Copies one group's counts out of `res`.
+static void mp_collect(sfm_gpu_ctx*, const int32_t* res, int g, int32_t* n_good, int32_t* n_inliers)
 {
-    double out_sum = 0.0, pts_sum = 0.0;
-    int out_cnt = 0;
     for (int i = 0; i < g; ++i) {
         n_good[i] = res[2 * i];
         n_inliers[i] = res[2 * i + 1];
-        if (res[2 * i + 1] > 0) {
-            out_sum += res[2 * i] - res[2 * i + 1];
-            pts_sum += res[2 * i];
-            ++out_cnt;
-        }
-    }
-    if (out_cnt > 0) {  // sizes the next call's scoring stages
-        ctx->hint_outliers = out_sum / out_cnt;
-        ctx->hint_points = pts_sum / out_cnt;
     }
 }
 
@@ -715,11 +688,37 @@ static int match_pairs_impl(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int 
         return ctx->fail(SFM_GPU_ERR_ARG, "null pointer or negative count");
     if (n_pairs == 0) return SFM_GPU_OK;
     MpPlan pl;
-    int rc = mp_plan(ctx, pl, images, n_images, pairs, n_pairs, params, inlier_matches != nullptr, match_capacity);
+    // the pose needs every pair's inlier records on the device, wanted by the caller or not
+    const bool want_records = inlier_matches != nullptr || pose != nullptr;
+    if (!inlier_matches) {
+        match_capacity = 1;
+        for (int p = 0; p < n_pairs; ++p) {
+            const int q = pairs[2 * p];
+            if (q >= 0 && q < n_images && images[q]) match_capacity = std::max(match_capacity, images[q]->d.n);
+        }
+    }
+    int rc = mp_plan(ctx, pl, images, n_images, pairs, n_pairs, params, want_records, match_capacity);
     if (rc) return rc;
     rc = mp_reserve(ctx, pl);
     if (rc) return rc;
     hipStream_t s = ctx->stream;
+    // second RANSAC of the pose (main.cpp:418): findEssentialMat(pointsL, pointsR, K, RANSAC) with
+    // OpenCV's defaults prob 0.999, threshold 1.0, at most 1000 iterations
+    RansacParams rp2 = pl.rp;
+    RansacProb proto2;
+    const int hyp_cap2 = 1000;
+    size_t per_pair2 = 0;
+    if (pose) {
+        rp2.model = SFM_GPU_MODEL_ESSENTIAL;
+        rp2.mode = SFM_GPU_RANSAC_ADAPTIVE;
+        rp2.prob = 0.999;
+        rp2.threshold_px = 1.0;
+        rp2.max_iters = hyp_cap2;
+        rc = fill_params(ctx, proto2, rp2);
+        if (rc) return rc;
+        per_pair2 = ransac_ws_bytes(pl.nq_max, hyp_cap2, proto2.m);
+        SFM_HIP(ctx, ctx->rs_models2.reserve(per_pair2 * (size_t)pl.group + (size_t)R_COUNT * 4 * pl.group));
+    }
     SFM_HIP(ctx, ctx->mp_stage_sync.reserve(mp_stage_bytes(pl.group)));
     SFM_HIP(ctx, ctx->mp_res_sync.reserve(8 * (size_t)pl.group));
     std::vector<PairDev> pds;
@@ -727,7 +726,7 @@ static int match_pairs_impl(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int 
         const int g = std::min(pl.group, n_pairs - g0);
         ctx->up_stage = &ctx->mp_stage_sync;  // the previous group has been waited for
         ctx->up_used = 0;
-        rc = mp_enqueue(ctx, pl, images, pairs, g0, g, params, inlier_matches != nullptr, match_capacity, pds,
+        rc = mp_enqueue(ctx, pl, images, pairs, g0, g, params, want_records, match_capacity, pds,
                         ctx->mp_res_sync.p);
         ctx->up_stage = nullptr;
         if (rc) return rc;
@@ -742,10 +741,30 @@ static int match_pairs_impl(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int 
             SFM_HIP(ctx, hipStreamSynchronize(s));
         }
         if (pose) {
-            // the group's problem descriptors are still on the device (pds[0].prob is the first)
-            rc = pose_for_pairs(ctx, pds[0].prob, g, n_inliers + g0, params->K, pose->distance_thresh,
+            // main.cpp:400-420 for every pair: a second essential-matrix RANSAC over the
+            // pair's selectMatches, then recoverPose with that matrix on all of them.
+            // The group's pair descriptors are still on the device (pds[0].prob points
+            // into the same block, behind them).
+            const PairDev* dpds = (const PairDev*)(ctx->jobs.as<char>() + align_up(sizeof(KnnJob) * (size_t)g, 64));
+            SFM_HIP(ctx, launch_gather_inlier_points(s, dpds, g, pl.nq_max));
+            std::vector<RansacProb> probs2(g, proto2);
+            int32_t* res2 = (int32_t*)(ctx->rs_models2.as<char>() + per_pair2 * (size_t)pl.group);
+            for (int i = 0; i < g; ++i) {
+                RansacProb& pb = probs2[i];
+                pb.px1 = pds[i].px1;
+                pb.px2 = pds[i].px2;
+                pb.n_ptr = pds[i].n_inliers;
+                carve_ransac(pb, ctx->rs_models2.as<char>() + per_pair2 * i, pl.nq_max, hyp_cap2, proto2.m);
+                pb.result = res2 + (size_t)R_COUNT * i;
+            }
+            std::vector<int32_t> results2;
+            rc = ransac_batch(ctx, probs2, pl.nq_max, hyp_cap2, rp2, nullptr, results2, true);
+            if (rc) return rc;
+            std::vector<int32_t> ok2(g);
+            for (int i = 0; i < g; ++i) ok2[i] = results2[(size_t)i * R_COUNT + R_OK] ? results2[(size_t)i * R_COUNT + R_NINL] : 0;
+            rc = pose_for_pairs(ctx, ctx->rs_misc.as<RansacProb>(), g, ok2.data(), params->K, pose->distance_thresh,
                                 pose->models ? pose->models + 9 * (size_t)g0 : nullptr, pose->R + 9 * (size_t)g0,
-                                pose->t + 3 * (size_t)g0, pose->n_pose_good + g0, pl.nq_max);
+                                pose->t + 3 * (size_t)g0, pose->n_pose_good + g0, pl.nq_max, true);
             if (rc) return rc;
         }
     }

@@ -23,6 +23,9 @@ enum {
     R_NLIST = 10,  // candidate models listed for the batch being scored
     R_MAXABS = 11, // largest |coordinate| of the problem's points, float32 bits
     R_BOUND = 12,  // largest complete inlier count known so far in the batch being scored
+    R_S1 = 13,     // staged scoring: points [0, R_S1) are scored for every listed model first ...
+    R_MID = 14,    // ... then [R_S1, R_MID) for what the first cut leaves, then the rest (multiples of 128, or n)
+    R_S0 = 15,     // the opening stretch [0, R_S0) of the first stage, from which R_S1 is chosen
     R_COUNT = 16
 };
 
@@ -111,15 +114,17 @@ hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int
 // sample rows itself instead of reading a table made by launch_ransac_table_fixed
 hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp,
                                int gen_rows = 0);
-// prune > 0: every model is first scored on the first `prune` points, then the
-// models that provably cannot reach the best count are dropped (their counts
-// stay partial) and the rest go on; the selected model, its count and the mask
-// are the same as with prune = 0.
+// staged (fixed-count mode): every model is scored on an opening stretch of the
+// points, whose best partial count tells each problem how many outliers to
+// expect; the first stage is extended to outnumber them, the models that provably
+// cannot reach the best count are dropped (their counts stay partial) and the rest
+// go on, with a second cut further in.  All sizes are chosen per problem on the
+// device.  The selected model, its count and the mask are those of staged = false.
 // filter_mode: 1 = float32 filter with a rigorous bound in front of the double
 // precision test, 0 = double precision only (same counts).  prune_mode: 0 = never
 // drop a model, 1 = as described above, 2 = at most one cut.
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
-                               int n_hyp, int prune, int mid, int filter_mode, int prune_mode);
+                               int n_hyp, bool staged, int filter_mode, int prune_mode);
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
 
 // One image pair between the k-NN output and RANSAC (pair_kernels.hip).
@@ -158,7 +163,11 @@ hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_pr
 
 // recoverPose for the g problems at dprobs (essential model, stream drained,
 // masks final): pose.hip.  Pairs with n_inliers[i] <= 0 get n_pose_good = -1.
+// every_point: all of a problem's correspondences vote, not only its inliers.
 int pose_for_pairs(sfm_gpu_ctx* ctx, const RansacProb* dprobs, int g, const int32_t* n_inliers, const double* K,
                    double distance_thresh, double* models_out, double* R_out, double* t_out, int32_t* n_pose_good,
-                   int nq_max);
+                   int nq_max, bool every_point);
+// px1/px2 of every pair = the keypoint coordinates of its inlier matches (Point2f
+// widened to double, main.cpp:400-416): the input of a RANSAC over them
+hipError_t launch_gather_inlier_points(hipStream_t s, const PairDev* pairs, int n_pairs, int n_query_max);
 }  // namespace sfm

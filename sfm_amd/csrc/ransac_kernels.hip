@@ -1331,6 +1331,12 @@ __global__ void __launch_bounds__(ROOTS7_WAVES * 64) ransac_roots7_kernel(const 
     if (valid && k == 0) pb.nmodels[hyp] = __popc(mine);
 }
 
+// Staged scoring: points every listed model is scored on before the stages are sized.
+constexpr int SCORE_OPENING = 256;
+// The rest of the first stage runs as this many equal pieces per problem (measured 2 / 4 / pieces of 256
+// with idle workgroups beyond a problem's stage: 259 / 230 / 238 us at 25 % outliers, 82 / 77 / 93 us at 7 %).
+constexpr int SCORE_SPLIT = 4;
+
 // Lists the candidate models of hypotheses [hyp0, hyp0+n_hyp) densely
 // (entry = hyp*10 + q, scan order) and initialises their counts: 0 for an
 // existing model, -1 for none.  One workgroup per problem.
@@ -1389,6 +1395,7 @@ __global__ void __launch_bounds__(1024) ransac_compact_kernel(const RansacProb* 
     if (tid == 0) {
         pb.result[R_NLIST] = s_running;
         pb.result[R_BOUND] = 0;
+        pb.result[R_S0] = SCORE_OPENING;
     }
 }
 
@@ -1587,19 +1594,27 @@ __device__ __forceinline__ f2v filter_h_out(const PairTerms& t, const FilterCons
 // workgroup strides over further groups / chunks when the grid is smaller than
 // the work, keeping its models in registers from chunk to chunk.
 constexpr int SCORE_WAVES = 1;  // independent wavefronts per workgroup
+// The points a launch covers are [result[slot_begin], min(n, result[slot_end])) of
+// its problem (a slot < 0 stands for 0 / n), the models the first
+// min(R_NLIST, list_limit) of the list.
 template <int MODEL, bool STRIDED>
-__global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const RansacProb* __restrict__ probs, int chunk_pts,
-                                                          int use_filter, int chunk0, int pts_end)
+__global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const RansacProb* __restrict__ probs, int chunk_pts_arg,
+                                                          int use_filter, int slot_begin, int slot_end,
+                                                          int list_limit)
 {
     typedef const double __attribute__((address_space(4))) cdouble;
     typedef const f2v __attribute__((address_space(4))) cf2v;
     const RansacProb pb = probs[blockIdx.z];
-    const int nlist = __builtin_amdgcn_readfirstlane(pb.result[R_NLIST]);
+    const int nlist = min(__builtin_amdgcn_readfirstlane(pb.result[R_NLIST]), list_limit);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (((int)blockIdx.x * SCORE_WAVES + wv) * 64 >= nlist) return;
-    // this launch covers the points [chunk0 * chunk_pts, min(n, pts_end))
-    const int n = min(__builtin_amdgcn_readfirstlane(*pb.n_ptr), pts_end);
-    if ((chunk0 + (int)blockIdx.y) * chunk_pts >= n) return;  // chunk_pts is a multiple of 4
+    const int pts_begin = slot_begin >= 0 ? __builtin_amdgcn_readfirstlane(pb.result[slot_begin]) : 0;
+    int n = __builtin_amdgcn_readfirstlane(*pb.n_ptr);
+    if (slot_end >= 0) n = min(n, __builtin_amdgcn_readfirstlane(pb.result[slot_end]));
+    // chunk_pts_arg <= 0: the problem's stretch in equal pieces, one per grid row
+    const int chunk_pts = chunk_pts_arg > 0 ? chunk_pts_arg
+                                            : (((max(n - pts_begin, 0) + (int)gridDim.y - 1) / (int)gridDim.y + 3) & ~3);
+    if (pts_begin + (int)blockIdx.y * chunk_pts >= n) return;  // stage boundaries and chunk_pts are multiples of 4
     const int lane = threadIdx.x & 63;
     constexpr int QCAP = 40;
     __shared__ unsigned short parked_all[SCORE_WAVES * QCAP * 64];
@@ -1628,7 +1643,7 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
     for (int k = 0; k < 9; ++k) Mf[k] = (float)M[k];
     typedef const float __attribute__((address_space(4))) cfloat;
     cfloat* S = (cfloat*)(uintptr_t)pb.soa;
-    for (int i0 = (chunk0 + blockIdx.y) * chunk_pts; i0 < n; i0 += gridDim.y * chunk_pts) {
+    for (int i0 = pts_begin + blockIdx.y * chunk_pts; i0 < n; i0 += gridDim.y * chunk_pts) {
     const int i1 = min(n, i0 + chunk_pts);
     int i = i0;
     // Tests the filter cannot settle are parked per lane (offset within the
@@ -1690,13 +1705,59 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
     }  // groups
 }
 
+// Staged scoring, after every listed model has been scored on the opening stretch
+// [0, s0) of the points: the best partial count there estimates the inlier share
+// (lowered by two standard deviations of a count of s0 trials, since the best of
+// thousands of noisy counts flatters it), hence the outliers to expect.  The first
+// stage has to outnumber the outliers for the bound to drop anything: it is
+// extended to 1.3 x that estimate (at least 15 % of the points), in pieces of 128,
+// at most `cover` points (what the next launch's grid reaches); the second cut comes 35 % into the rest when
+// enough is left to pay for it.  One workgroup per problem.  Only the cost
+// depends on these choices, never the result.
+__global__ void __launch_bounds__(1024) ransac_plan_kernel(const RansacProb* __restrict__ probs, int cover,
+                                                           int one_cut)
+{
+    __shared__ int s_best;
+    const RansacProb pb = probs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int n = *pb.n_ptr;
+    const int nlist = pb.result[R_NLIST];
+    if (tid == 0) s_best = 0;
+    __syncthreads();
+    int best = 0;
+    for (int p = tid; p < nlist; p += 1024) best = max(best, pb.counts[pb.list[p]]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off));
+    if ((tid & 63) == 0) atomicMax(&s_best, best);
+    __syncthreads();
+    if (tid == 0) {
+        const int s0 = min(n, SCORE_OPENING);
+        int s1 = n, mid = n;
+        if (s0 > 0 && n > s0) {
+            const double fh = ((double)s_best + 1.0) / ((double)s0 + 2.0);
+            const double sd = sqrt(fmax(fh * (1.0 - fh), 0.0) / (double)s0);
+            const double ft = fmax(fh - 2.0 * sd, 0.0);
+            const double outl = (double)n * (1.0 - ft);
+            // at least 15 % of the points: with few outliers the cut is cheap to make a little
+            // later, and it then also drops the half-good models (samples with one wrong match)
+            s1 = ((int)fmax(1.3 * outl, 0.15 * (double)n) + 1 + 127) / 128 * 128;
+            s1 = max(s1, s0);
+            s1 = min(s1, max(cover, s0));
+            if (n - s1 < 128) s1 = n;  // not worth another launch: everything in the first stage
+            if (!one_cut && n - s1 >= 1024) mid = (s1 + (int)(0.35 * (double)(n - s1)) + 127) / 128 * 128;
+        }
+        pb.result[R_S1] = s1;
+        pb.result[R_MID] = mid;
+    }
+}
+
 // Between two scoring stages of a fixed-count batch (points [0, pts_done) are
 // counted for every listed model): the listed model with the largest partial
 // count is completed here over the remaining points, which gives a lower bound
 // B on the count the winner will have; a model whose partial count plus all the
 // remaining points stays below B can neither win nor tie, so it leaves the
 // list.  Survivors keep their scan order.  One workgroup per problem.
-__global__ void __launch_bounds__(1024) ransac_prune_kernel(const RansacProb* __restrict__ probs, int pts_done)
+__global__ void __launch_bounds__(1024) ransac_prune_kernel(const RansacProb* __restrict__ probs, int slot_done)
 {
     __shared__ unsigned long long sh[16];
     __shared__ int wsum[16];
@@ -1705,6 +1766,7 @@ __global__ void __launch_bounds__(1024) ransac_prune_kernel(const RansacProb* __
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = *pb.n_ptr;
     const int nlist = pb.result[R_NLIST];
+    const int pts_done = pb.result[slot_done];
     if (pts_done >= n || nlist <= 0) return;
     // the listed model with the largest partial count
     unsigned long long best = 0;
@@ -1970,7 +2032,7 @@ hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_pro
     return hipGetLastError();
 }
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
-                               int n_hyp, int prune, int mid, int filter_mode, int prune_mode)
+                               int n_hyp, bool staged, int filter_mode, int prune_mode)
 {
     const int maxm = model == SFM_GPU_MODEL_ESSENTIAL ? 10 : 3;
     hipLaunchKernelGGL(ransac_compact_kernel, dim3(n_prob), dim3(1024), 0, s, probs, hyp0, n_hyp, maxm);
@@ -1978,60 +2040,56 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     const int n_chunks = (cap + chunk - 1) / chunk > 0 ? (cap + chunk - 1) / chunk : 1;
     const unsigned groups = (unsigned)(((size_t)n_hyp * maxm + 63) / 64);
     // strided: the grid is smaller than the work and its workgroups loop
-    auto score = [&](int chunk_pts, int chunk0, int chunks, unsigned gx, int pts_end, bool strided) {
+    auto score = [&](int chunk_pts, int slot_begin, int slot_end, int chunks, unsigned gx, int list_limit,
+                     bool strided) {
         const dim3 grid((gx + SCORE_WAVES - 1) / SCORE_WAVES, chunks, n_prob), block(SCORE_WAVES * 64);
         const int f = filter_mode;
         if (model == SFM_GPU_MODEL_ESSENTIAL) {
             if (strided)
                 hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL, true>), grid, block, 0, s, probs,
-                                   chunk_pts, f, chunk0, pts_end);
+                                   chunk_pts, f, slot_begin, slot_end, list_limit);
             else
                 hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL, false>), grid, block, 0, s, probs,
-                                   chunk_pts, f, chunk0, pts_end);
+                                   chunk_pts, f, slot_begin, slot_end, list_limit);
         } else {
             if (strided)
                 hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL, true>), grid, block, 0, s, probs,
-                                   chunk_pts, f, chunk0, pts_end);
+                                   chunk_pts, f, slot_begin, slot_end, list_limit);
             else
                 hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL, false>), grid, block, 0, s, probs,
-                                   chunk_pts, f, chunk0, pts_end);
+                                   chunk_pts, f, slot_begin, slot_end, list_limit);
         }
     };
-    // Stages with a pruning step between them: every model on the first
-    // `prune` points (in half chunks: a single round of workgroups balances
-    // better when they are short), the survivors on the rest.  The bound only
-    // bites when that sample outnumbers the outliers among the points; the
-    // caller sizes it from what it knows about them.  The survivors of the
-    // first cut are still of mixed quality (anything above roughly half the
-    // winner's inlier rate), so when the caller also knows about how many
-    // points there are it names a point `mid` inside the rest where the list is
-    // cut again; by then only models close to the winner remain.
-    // `prune` = points of the first stage, rounded up to a multiple of 128 and
-    // split into equal pieces of at most 256
-    const int p1 = (prune + 127) / 128 * 128;
-    const int p_end = n_chunks * chunk;
-    if (prune > 0 && prune_mode && p_end > p1) {
-        const int ny = (p1 + 255) / 256;
-        score(((p1 + ny - 1) / ny + 3) & ~3, 0, ny, groups, p1, false);
-        hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, p1);
+    // Stages with a pruning step between them.  Every model runs over an opening
+    // stretch, from which each problem estimates its outliers
+    // (ransac_plan_kernel); the first stage is extended to outnumber them, the
+    // bound drops what cannot win, and the survivors -- still of mixed quality,
+    // anything above roughly half the winner's inlier rate -- are cut a second
+    // time further in; by then only models close to the winner remain.  The
+    // stage boundaries live in the problems' result blocks; a launch only fixes
+    // how far its grid reaches.
+    if (staged && prune_mode && cap >= 1024) {
+        score(SCORE_OPENING, -1, R_S0, 1, groups, INT_MAX, false);
+        // the first stage may take up to a quarter of the capacity: with the ratio
+        // test leaving well under half of the queries, that covers outlier shares
+        // up to about one half, beyond which the bound has nothing to drop anyway
+        const int cover = std::max(2 * SCORE_OPENING, (cap / 4 + 255) / 256 * 256);
+        hipLaunchKernelGGL(ransac_plan_kernel, dim3(n_prob), dim3(1024), 0, s, probs, cover, prune_mode == 2 ? 1 : 0);
+        score(0, R_S0, R_S1, SCORE_SPLIT, groups, INT_MAX, false);
+        hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, (int)R_S1);
         // the survivors are few: pieces of 128 points, and a grid an eighth of
-        // the list wide (a sixteenth after the second cut) and at most 32 pieces
-        // deep that strides over whatever is left (measured best among widths
-        // 1/2..1/32, depths 8..64 and pieces of 32..128 points)
-        int pm = (mid + 127) / 128 * 128;
-        if (!(prune_mode == 1 && pm > p1 && pm < p_end)) pm = 0;
-        if (pm) {
-            const int c = (pm - p1) / 128;
-            score(128, p1 / 128, c < 32 ? c : 32, (groups + 7) / 8, pm, true);
-            hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, pm);
-            const int c2 = (p_end - pm) / 128;
-            score(128, pm / 128, c2 < 32 ? c2 : 32, (groups + 15) / 16, INT_MAX, true);
+        // the list wide (a sixteenth after the second cut) that strides over
+        // whatever is left
+        const int depth = std::max(1, std::min(32, cap / 1024));
+        if (prune_mode == 1) {
+            score(128, R_S1, R_MID, depth, (groups + 7) / 8, INT_MAX, true);
+            hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, (int)R_MID);
+            score(128, R_MID, -1, std::min(32, 2 * depth), (groups + 15) / 16, INT_MAX, true);
         } else {
-            const int c = (p_end - p1) / 128;
-            score(128, p1 / 128, c < 32 ? c : 32, (groups + 7) / 8, INT_MAX, true);
+            score(128, R_S1, -1, std::min(32, 2 * depth), (groups + 7) / 8, INT_MAX, true);
         }
     } else {
-        score(chunk, 0, n_chunks, groups, INT_MAX, false);
+        score(chunk, -1, -1, n_chunks, groups, INT_MAX, false);
     }
     return hipGetLastError();
 }

@@ -134,6 +134,7 @@ struct sfm_gpu_ctx {
     sfm::DevBuf partial, out, counts, redo, jobs, flags, prepjobs;
     // ransac workspaces
     sfm::DevBuf rs_pts, rs_table, rs_models, rs_counts, rs_mask, rs_misc;
+    sfm::DevBuf rs_models2;  // workspace of the pose's second RANSAC (sfm_gpu_match_pairs_pose)
     sfm::PinnedBuf pin_a, pin_b;  // host staging for results / counts / descriptors of jobs
     // match_pairs workspaces
     sfm::DevBuf mp_good, mp_pts, mp_ngood;
@@ -187,9 +188,6 @@ struct sfm_gpu_ctx {
     // once another context has asked to wait for it (sfm_gpu_stream_wait_front)
     hipEvent_t front_ev = nullptr;
     bool front_recorded = false;
-    // outliers (points - inliers) per problem at the end of the last RANSAC call, -1: none yet
-    double hint_outliers = -1.0;
-    double hint_points = -1.0;  // correspondences per problem in the previous call (as hint_outliers)
 
     // device pointers of the last sfm_gpu_ransac call, for the test hooks
     const int32_t* dbg_table = nullptr;

@@ -283,7 +283,7 @@ void sfm_gpu_destroy(sfm_gpu_ctx* c)
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->raw_q, &c->raw_t, &c->partial, &c->out, &c->counts, &c->redo, &c->jobs,
                       &c->flags, &c->prepjobs, &c->rs_pts, &c->rs_table, &c->rs_models, &c->rs_counts, &c->rs_mask,
-                      &c->rs_misc, &c->mp_good, &c->mp_pts, &c->mp_ngood, &c->pose_in, &c->pose_out, &c->pnp_ws};
+                      &c->rs_misc, &c->rs_models2, &c->mp_good, &c->mp_pts, &c->mp_ngood, &c->pose_in, &c->pose_out, &c->pnp_ws};
     for (DevBuf* b : bufs) b->release();
     c->tmp_q.release();
     c->tmp_t.release();

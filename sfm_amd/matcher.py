@@ -397,11 +397,12 @@ def match_pairs(ctx, images, pairs, K, ratio=0.7, model=MODEL_ESSENTIAL, mode=RA
 
 def match_pairs_pose(ctx, images, pairs, K, ratio=0.7, mode=RANSAC_ADAPTIVE, prob=0.99, threshold=1.0,
                      max_iters=1000, n_hyp=0, distanceThresh=50.0, want_matches=False):
-    """match_pairs (essential model) followed per pair by recoverPose on the
-    pair's inlier matches with the pair's own essential matrix (main.cpp:400-420
-    for every pair instead of the first).  Returns a dict: n_good, n_inliers,
-    E [n,3,3], R [n,3,3], t [n,3], n_pose_good [n] (-1: no model), and
-    inlier_matches when asked for."""
+    """match_pairs (essential model) followed per pair by main.cpp:400-420: a
+    second findEssentialMat (prob 0.999, 1 px, 1000 iterations) over the pair's
+    inlier matches and recoverPose with that matrix on all of them (the
+    reference does this for the first pair).  Returns a dict: n_good, n_inliers,
+    E [n,3,3] (of the second RANSAC), R [n,3,3], t [n,3], n_pose_good [n]
+    (-1: no model), and inlier_matches when asked for."""
     pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
     n_pairs = pairs.shape[0]
     arr = (ctypes.c_void_p * len(images))(*[im.handle for im in images])

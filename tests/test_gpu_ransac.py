@@ -243,21 +243,22 @@ def test_pruned_scoring_selects_the_same_model(gpu_ctx, oracle, model, seed, n, 
     top = oc == oc.max()
     assert (counts[top] == oc[top]).all()
     if n >= 3000 and frac >= 0.9:
-        # the first stage (1/8 of the points) outnumbers the outliers, so the
-        # bound bites: most models were left with partial counts
+        # the first stretch outnumbers the outliers, so the bound bites: most
+        # models were left with partial counts
         assert (counts < oc)[oc >= 0].mean() > 0.3
 
 
-def test_first_stage_size_follows_history_but_not_the_result(gpu_ctx, oracle):
-    """The first scoring stage is sized from the outliers the previous call ended
-    with; whatever that guess is, the answer is the exhaustive loop's."""
+def test_stage_sizes_chosen_on_the_device_never_change_the_result(gpu_ctx, oracle):
+    """The scoring stages are sized per problem on the device from a first group
+    of models scored on every point; calls with very different outlier shares in
+    any order give the exhaustive loop's answer each time."""
     pa1, pa2, _, _ = synth.two_view(6000, 61, inlier_frac=0.95)
     pb1, pb2, _, _ = synth.two_view(6000, 62, inlier_frac=0.3)
     want = {}
     for name, (p1, p2) in (("a", (pa1, pa2)), ("b", (pb1, pb2))):
         o = oracle.ransac(p1, p2, None, model=1, prob=0.99, threshold=3.0, fixed_count=192)
         want[name] = (o["mask"], o["model"], o["n_inliers"])
-    for name in ("a", "b", "a", "a", "b", "b", "a"):   # every kind of stale hint
+    for name in ("a", "b", "a", "a", "b", "b", "a"):   # nothing carries over between calls
         p1, p2 = (pa1, pa2) if name == "a" else (pb1, pb2)
         F, mask, r = matcher.findFundamentalMat(gpu_ctx, p1, p2, ransacReprojThreshold=3.0, confidence=0.99,
                                                 mode=matcher.RANSAC_FIXED, n_hyp=192)

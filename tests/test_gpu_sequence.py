@@ -71,8 +71,13 @@ def test_match_pairs_pose_equals_recover_pose_per_pair(gpu_ctx, oracle, mode):
             assert res["n_pose_good"][p] == -1 and not res["R"][p].any() and not res["t"][p].any()
             continue
         with_pose += 1
-        assert res["E"][p].tobytes() == np.asarray(r["model"]).tobytes()
-        o = oracle.recover_pose(r["model"], p1, p2, synth.REF_K)
+        # main.cpp:418-420: a second RANSAC (OpenCV's defaults: 0.999, 1 px, 1000 iterations)
+        # over the selected matches gives the matrix recoverPose decomposes, and every
+        # selected match votes
+        r2 = oracle.ransac(p1, p2, synth.REF_K, model=0, prob=0.999, threshold=1.0, max_iters=1000)
+        assert r2["ok"] == 1
+        assert res["E"][p].tobytes() == np.asarray(r2["model"]).tobytes()
+        o = oracle.recover_pose(r2["model"], p1, p2, synth.REF_K)
         assert res["n_pose_good"][p] == o["n_good"]
         assert res["R"][p].tobytes() == o["R"].tobytes()
         assert res["t"][p].tobytes() == o["t"].reshape(3).tobytes()
