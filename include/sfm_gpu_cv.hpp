@@ -7,6 +7,8 @@
 //   knnMatch          matcher->knnMatch(descL, descR, matches, 2)        main.cpp:181-184
 //   findEssentialMat  findEssentialMat(p1, p2, K, FM_RANSAC, prob, thr, mask)
 //                                                     main.cpp:224, :418; bundle_adjustment.h:79
+//   findFundamentalMat  findFundamentalMat(p1, p2, FM_RANSAC, thr, confidence, mask): the call BASELINE's
+//                     single-pair configuration names; the reference itself only calls findEssentialMat
 //   recoverPose       recoverPose(E, p1, p2, K, R, T)       main.cpp:420; bundle_adjustment.h:80
 //   trackJoin         the nested loop over two match lists              main.cpp:442-456
 //   trackJoinSequence that loop for every image of the sequence         main.cpp:432-456
@@ -84,6 +86,33 @@ public:
             return cv::Mat(3 * k, 3, CV_64F, all).clone();
         }
         return cv::Mat(3, 3, CV_64F, E).clone();
+    }
+
+    // cv::findFundamentalMat(points1, points2, FM_RANSAC, ransacReprojThreshold, confidence, mask):
+    // seven-point samples, symmetric epipolar distance, F33 = 1.  With exactly seven points the
+    // result stacks every candidate (3k x 3); fewer than seven give an empty matrix; 8..14 points
+    // make OpenCV switch to LMedS, which this path does not have (cv::Exception).
+    cv::Mat findFundamentalMat(const std::vector<cv::Point2d>& p1, const std::vector<cv::Point2d>& p2,
+                               double ransacReprojThreshold = 3.0, double confidence = 0.99,
+                               std::vector<uchar>* mask = nullptr, int maxIters = 1000) const
+    {
+        CV_Assert(p1.size() == p2.size());
+        double F[9];
+        int32_t ok = 0;
+        std::vector<uchar> m(p1.size(), 0);
+        const int n = (int)p1.size();
+        check(sfm_gpu_ransac(ctx_, n ? &p1[0].x : nullptr, n ? &p2[0].x : nullptr, n, nullptr,
+                             SFM_GPU_MODEL_FUNDAMENTAL, confidence, ransacReprojThreshold, maxIters,
+                             SFM_GPU_RANSAC_ADAPTIVE, nullptr, 0, m.data(), F, nullptr, nullptr, &ok));
+        if (!ok) return cv::Mat();
+        if (mask) *mask = m;
+        if (n == 7) {
+            double all[27];
+            int32_t k = 0;
+            check(sfm_gpu_ransac_candidates(ctx_, all, 3, &k));
+            return cv::Mat(3 * k, 3, CV_64F, all).clone();
+        }
+        return cv::Mat(3, 3, CV_64F, F).clone();
     }
 
     // main.cpp:420, bundle_adjustment.h:80

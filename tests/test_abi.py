@@ -90,3 +90,17 @@ def test_headers_are_plain_c_and_a_c_host_links(tmp_path):
     cpp = tmp_path / "host.cpp"
     cpp.write_text('#include "sfm_gpu.h"\n#include "sfm_gpu_debug.h"\nint main() { return sfm_gpu_version() ? 0 : 1; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(cpp)])
+
+
+def test_opencv_facing_sources_parse_against_declaration_only_headers():
+    """include/sfm_gpu_cv.hpp and tools/opencv_crosscheck.cpp need OpenCV, which this
+    machine lacks.  tests/mock_opencv holds declarations (no bodies, nothing is
+    linked or run) of the few OpenCV names the two files use, enough for
+    `g++ -fsyntax-only` to find typos, missing includes and calls of C-ABI
+    functions with the wrong arguments.  Syntax only: it proves nothing about
+    OpenCV's behaviour."""
+    import subprocess
+    p = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
+                        "-I", os.path.join(ROOT, "tests", "mock_opencv"), "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tools", "opencv_crosscheck.cpp")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-4000:]

@@ -10,10 +10,15 @@
 //   cv::BFMatcher(NORM_L2).knnMatch(q, t, matches, 2)      main.cpp:181-184 (exact brute force)
 //   ratio test in double                                    main.cpp:189-197
 //   cv::findEssentialMat(p1, p2, K, RANSAC, 0.99, 1.0, mask)      main.cpp:224
+//   cv::findFundamentalMat(p1, p2, FM_RANSAC, 3.0, 0.99, mask)     (BASELINE's single-pair configuration)
 //   cv::recoverPose(E, p1, p2, K, R, t)                            main.cpp:420
+// and one experiment on OpenCV alone: which floating-point form findEssentialMat
+// uses to normalise pixel coordinates (probe_normalisation below).
 //   cv::solvePnPRansac(X, u, K, zeros, r, t, false, 100, 8, 0.99, inl, SOLVEPNP_EPNP)
 //                                                        bundle_adjustment.h:154
+#include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -111,6 +116,61 @@ int diff_essential(const sfm_gpu_cv::Matcher& gpu, int n, double frac, unsigned 
     return bad;
 }
 
+int diff_fundamental(const sfm_gpu_cv::Matcher& gpu, int n, double frac, unsigned seed)
+{
+    cv::Mat K = (cv::Mat_<double>(3, 3) << 2892.33, 0, 823.205, 0, 2883.18, 619.071, 0, 0, 1);
+    std::vector<cv::Point2d> p1, p2;
+    two_view(n, frac, seed, K, p1, p2);
+    std::vector<uchar> ma(n, 0), mb(n, 0);
+    cv::Mat Fa = cv::findFundamentalMat(p1, p2, cv::FM_RANSAC, 3.0, 0.99, ma);
+    cv::Mat Fb = gpu.findFundamentalMat(p1, p2, 3.0, 0.99, &mb);
+    int bad = Fa.empty() != Fb.empty();
+    for (int i = 0; i < n; ++i) bad += (ma[i] != 0) != (mb[i] != 0);
+    double df = -1;
+    if (!Fa.empty() && !Fb.empty() && Fa.rows == 3 && Fb.rows == 3) df = cv::norm(Fa - Fb) / cv::norm(Fa);
+    std::printf("findFundamentalMat n=%d inliers %.0f%%: %d mask bytes differ, |dF|/|F| = %.3g\n", n, frac * 100, bad,
+                df);
+    return bad;
+}
+
+// Which arithmetic does cv::findEssentialMat use to normalise pixels?  The library
+// (and its CPU oracle) compute x = (u - cx) / fx.  A matrix-expression evaluation
+// of (points - pp) / focal may instead multiply by a reciprocal, x = u * (1/fx) +
+// (-cx * (1/fx)).  The two differ in the last bit of some coordinates, which can
+// move a borderline inlier.  OpenCV answers by itself: with an identity camera
+// matrix its own normalisation is exact, so calling it on points normalised
+// beforehand in either form and comparing the essential matrices of a five-point
+// call (no RANSAC, every candidate returned) with those of the ordinary call on
+// pixels shows which form the ordinary call applied.
+void probe_normalisation()
+{
+    cv::Mat K = (cv::Mat_<double>(3, 3) << 2892.33, 0, 823.205, 0, 2883.18, 619.071, 0, 0, 1);
+    cv::Mat I = (cv::Mat_<double>(3, 3) << 1, 0, 0, 0, 1, 0, 0, 0, 1);
+    const double fx = 2892.33, fy = 2883.18, cx = 823.205, cy = 619.071;
+    int same_div = 0, same_mul = 0, trials = 0;
+    for (unsigned seed = 1; seed <= 50; ++seed) {
+        std::vector<cv::Point2d> p1, p2, d1, d2, m1, m2;
+        two_view(5, 1.0, 900 + seed, K, p1, p2);
+        for (int i = 0; i < 5; ++i) {
+            d1.emplace_back((p1[i].x - cx) / fx, (p1[i].y - cy) / fy);
+            d2.emplace_back((p2[i].x - cx) / fx, (p2[i].y - cy) / fy);
+            const double ix = 1.0 / fx, iy = 1.0 / fy;
+            m1.emplace_back(p1[i].x * ix + (-cx * ix), p1[i].y * iy + (-cy * iy));
+            m2.emplace_back(p2[i].x * ix + (-cx * ix), p2[i].y * iy + (-cy * iy));
+        }
+        const double thr = 1.0 / ((fx + fy) / 2);
+        cv::Mat E = cv::findEssentialMat(p1, p2, K, cv::RANSAC, 0.99, 1.0);
+        cv::Mat Ed = cv::findEssentialMat(d1, d2, I, cv::RANSAC, 0.99, thr);
+        cv::Mat Em = cv::findEssentialMat(m1, m2, I, cv::RANSAC, 0.99, thr);
+        if (E.empty()) continue;
+        ++trials;
+        same_div += E.rows == Ed.rows && cv::norm(E - Ed) == 0;
+        same_mul += E.rows == Em.rows && cv::norm(E - Em) == 0;
+    }
+    std::printf("normalisation probe, %d five-point calls: identical to (u-cx)/fx in %d, to u*(1/fx)+(-cx/fx) in %d\n"
+                "  (the library and its oracle use the first form)\n", trials, same_div, same_mul);
+}
+
 int diff_pnp(const sfm_gpu_cv::Matcher& gpu, int n, double out_frac, unsigned seed)
 {
     cv::Mat K = (cv::Mat_<double>(3, 3) << 2892.33, 0, 823.205, 0, 2883.18, 619.071, 0, 0, 1);
@@ -148,8 +208,11 @@ int main()
         bad += diff_knn(gpu, nq, nt, 100 + nq);
     for (auto [n, f] : {std::pair<int, double>{5, 1.0}, {64, 0.9}, {3000, 0.9}, {3000, 0.5}, {12000, 0.3}})
         bad += diff_essential(gpu, n, f, 200 + n);
+    for (auto [n, f] : {std::pair<int, double>{7, 1.0}, {64, 0.9}, {3000, 0.9}, {3000, 0.5}})
+        bad += diff_fundamental(gpu, n, f, 400 + n);
     for (auto [n, f] : {std::pair<int, double>{5, 0.0}, {40, 0.2}, {3000, 0.3}})
         bad += diff_pnp(gpu, n, f, 300 + n);
+    probe_normalisation();
     std::printf("%s: %d differences\n", bad ? "DIFFERENT" : "identical", bad);
     return bad ? 1 : 0;
 }
