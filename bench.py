@@ -202,6 +202,11 @@ def main():
                     help="seconds the blocks after the timed region may take before the line is printed without them")
     ap.add_argument("--allpairs-views", type=int, default=64)
     ap.add_argument("--allpairs-desc", type=int, default=20000)
+    ap.add_argument("--allpairs-window", type=int, default=0,
+                    help="0: every view sees one common scene (the 64-view configuration); w > 0: a long capture in "
+                         "which view i overlaps views i-w..i+w only (the 1000-image configuration: --allpairs-views "
+                         "1000 --allpairs-desc 8192 --allpairs-window 5)")
+    ap.add_argument("--allpairs-reps", type=int, default=3, help="runs of the exhaustive block (the first sizes workspaces)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -781,9 +786,14 @@ def main():
             from sfm_amd import allpairs, synth
             V, nd = args.allpairs_views, args.allpairs_desc
             lo, hi = allpairs.owned_range(V, world, rank)
-            descs_v, kps_v, _ = synth.image_sequence(hi, nd, 4242, shared=0.4)   # images lo..hi-1 are this rank's
+            if args.allpairs_window > 0:
+                descs_v, kps_v = synth.window_sequence(lo, hi, nd, 4242, shared=0.4, window=args.allpairs_window)
+                own = range(hi - lo)
+            else:
+                descs_v, kps_v, _ = synth.image_sequence(hi, nd, 4242, shared=0.4)   # images lo..hi-1 are this rank's
+                own = range(lo, hi)
             with torch.cuda.stream(stream):
-                local = [(torch.from_numpy(descs_v[i]).cuda(), torch.from_numpy(kps_v[i]).cuda()) for i in range(lo, hi)]
+                local = [(torch.from_numpy(descs_v[i]).cuda(), torch.from_numpy(kps_v[i]).cuda()) for i in own]
             stream.synchronize()
             del descs_v, kps_v
             be = allpairs.GpuBackend(ctx, K=synth.REF_K, model=matcher.MODEL_ESSENTIAL, mode=matcher.RANSAC_ADAPTIVE,
@@ -791,7 +801,7 @@ def main():
             dev = torch.device("cuda", local_rank)
             best = None
             with torch.cuda.stream(stream):
-                for rep in range(3):   # the first run sizes the workspaces
+                for rep in range(max(2, args.allpairs_reps)):   # the first run sizes the workspaces
                     fence()
                     t3 = time.perf_counter()
                     ap_pairs, ap_good, ap_inl, ap_stats = allpairs.match_all_pairs(local, V, be, mode="all", device=dev,
@@ -805,13 +815,21 @@ def main():
                     if rep > 0:
                         best = dt3 if best is None else min(best, dt3)
             adj = [int(ap_inl[i, i + 1]) for i in range(V - 1)]
+            per8 = (V + 7) // 8   # what one all-gather delivers to each of 8 ranks: their slabs of ceil(V/8) images
             allp = {
-                "workload": "configs[3]: %d views x %d descriptors, all %d pairs, kNN k=2 + ratio 0.7 + essential RANSAC "
-                            "(adaptive, prob 0.99, 1 px), descriptors resident in HBM as float32" % (V, nd, len(ap_pairs)),
+                "workload": "%s: %d views x %d descriptors, all %d pairs, kNN k=2 + ratio 0.7 + essential RANSAC "
+                            "(adaptive, prob 0.99, 1 px), descriptors resident in HBM as float32" %
+                            ("configs[4]" if args.allpairs_window > 0 else "configs[3]", V, nd, len(ap_pairs)),
+                "sweep_tops_algorithmic": round(2.0 * nd * nd * 128 * len(ap_pairs) / best / 1e12, 1),
+                "sweep_frac_of_int8_peak_end_to_end": round(2.0 * nd * nd * 128 * len(ap_pairs) / best / 1e12
+                                                            / INT8_DENSE_PEAK_TOPS, 4),
+                "gathered_bytes_per_rank_at_8_ranks": int(8 * per8 * (ap_stats["blob_bytes"] + 4)),
+                "pairs_with_inliers": int((ap_inl > 0).sum()),
                 "scaling": "strong", "n_gpus": joined, "pairs": int(len(ap_pairs)),
                 "seconds": round(best, 5), "pairs_per_s": round(len(ap_pairs) / best, 1),
                 "includes": "descriptor conversion where the images live, all-gather of the prepared images, dealt pair "
-                            "list, matching, all-reduce of the V x V count matrices (max over ranks, best of 2 runs)",
+                            "list, matching, all-reduce of the V x V count matrices (max over ranks, best of %d runs)"
+                            % (max(2, args.allpairs_reps) - 1),
                 "gathered_bytes_per_rank": ap_stats["gathered_bytes"], "collective_backend": backend if world > 1 else None,
                 "inliers_neighbouring_views_min_max": [min(adj), max(adj)] if adj else None,
                 "inliers_farthest_pair": int(ap_inl[0, V - 1]) if V > 1 else None,

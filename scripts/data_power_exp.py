@@ -14,6 +14,12 @@ def main():
     cases = {
         "sift-like": (sift_q, sift_t),
         "uniform random": (rng.integers(0, 256, (n, 128)).astype(np.float32), rng.integers(0, 256, (n, 128)).astype(np.float32)),
+        # the same rows moved by a constant (clipped): stored bytes are value - 128, so +128 makes the stored
+        # operands small numbers around zero instead of numbers around -128
+        "sift+128 both": (np.minimum(sift_q + 128, 255), np.minimum(sift_t + 128, 255)),
+        "sift q, sift+128 t": (sift_q, np.minimum(sift_t + 128, 255)),
+        "sift+128 q, sift t": (np.minimum(sift_q + 128, 255), sift_t),
+        "sift+64 both": (np.minimum(sift_q + 64, 255), np.minimum(sift_t + 64, 255)),
         "q=0 t=0": (np.zeros((n, 128), np.float32), np.zeros((n, 128), np.float32)),
         "q=255 t=0": (np.full((n, 128), 255, np.float32), np.zeros((n, 128), np.float32)),
         "q=0 t=255": (np.zeros((n, 128), np.float32), np.full((n, 128), 255, np.float32)),

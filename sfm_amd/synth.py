@@ -158,3 +158,47 @@ def image_sequence(n_img, n_kp, seed, shared=0.5, sigma=6.0, noise_px=0.5, K=REF
         kps.append(k.astype(np.float32))
         ids.append(wid)
     return descs, kps, ids
+
+
+def window_sequence(first, last, n_kp, seed, shared=0.4, window=5, sigma=6.0, noise_px=0.5, K=REF_K):
+    """Images first..last-1 of an arbitrarily long capture along a straight baseline
+    (the shape of an exhaustive-matching job over hundreds of views): image i
+    shows pool points [i*step, i*step + n_sh), n_sh = shared * n_kp, step =
+    n_sh / window, so it shares (window - d) / window of them with image i +- d
+    and nothing beyond +- window.  Every pool point sits in front of the camera
+    that sees it first; camera i is displaced by 12 i along x.  Each image
+    depends only on (seed, i), so ranks can generate just the ones they own.
+    Returns (descs, kps)."""
+    n_sh = int(n_kp * shared)
+    step = max(1, n_sh // window)
+    Kinv = np.linalg.inv(K)
+    base_x = 12.0
+    descs, kps = [], []
+    for i in range(first, last):
+        idx = i * step + np.arange(n_sh)
+        # pool point idx: descriptor, pixel in the camera that sees it first, depth -- all from its own seed block
+        blk = idx // step                                  # camera that sees the point first
+        d = sift_like(n_kp, seed + 100 + i)
+        k_all = np.random.default_rng(seed + 7 * i + 3).uniform(0, 1, (n_kp, 2)) * np.array([IMG_W, IMG_H])
+        bd = np.empty((n_sh, 128), np.float32)
+        X = np.empty((n_sh, 3))
+        for b in np.unique(blk):
+            sel = blk == b
+            r = np.random.default_rng(seed * 1000003 + int(b))
+            pool_d = sift_like(step, seed * 31 + int(b) + 5)
+            pool_px = np.stack([r.uniform(200, IMG_W, step), r.uniform(0, IMG_H, step), np.ones(step)], 1)
+            pool_X = (pool_px @ Kinv.T) * r.uniform(425.0, 935.0, step)[:, None]
+            pool_X[:, 0] += base_x * b                     # world frame: camera b sits at x = 12 b
+            off = idx[sel] - b * step
+            bd[sel] = pool_d[off]
+            X[sel] = pool_X[off]
+        rng = np.random.default_rng(seed + 13 * i + 1)
+        Xc = X - np.array([base_x * i, 0.0, 0.0])
+        p = Xc @ K.T
+        p = p[:, :2] / p[:, 2:]
+        rows = rng.permutation(n_kp)[:n_sh]
+        d[rows] = np.clip(bd + np.rint(rng.normal(0.0, sigma, (n_sh, 128))), 0, 255).astype(np.float32)
+        k_all[rows] = p + rng.normal(0.0, noise_px, (n_sh, 2))
+        descs.append(d)
+        kps.append(k_all.astype(np.float32))
+    return descs, kps

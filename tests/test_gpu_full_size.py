@@ -123,3 +123,35 @@ def test_exhaustive_matcher_many_small_views(gpu_ctx, oracle):
     assert sorted(order.tolist()) == list(range(V))
     for im in images:
         im.close()
+
+
+def test_long_capture_of_8192_descriptor_views_sampled_against_oracle(gpu_ctx, oracle):
+    """The shape of the 1000-image exhaustive job at a size a test can afford:
+    200 views x 8192 descriptors of a long capture (each view overlaps its four
+    neighbours on either side), all 19 900 pairs through the exhaustive matcher
+    with the reference's own RANSAC call (essential, adaptive, 0.99, 1 px); 20
+    pairs -- 12 overlapping ones and 8 that share nothing -- are redone by the
+    oracle pipeline, survivor and inlier counts must agree; so must the band
+    structure of the whole count matrix."""
+    V, n = 200, 8192
+    descs, kps = synth.window_sequence(0, V, n, 4242, shared=0.4, window=5)
+    images = list(zip(descs, kps))
+    be = allpairs.GpuBackend(gpu_ctx, K=synth.REF_K, model=matcher.MODEL_ESSENTIAL, mode=matcher.RANSAC_ADAPTIVE,
+                             prob=0.99, threshold=1.0, max_iters=1000)
+    pairs, good, inl = allpairs.match_all_pairs(images, V, be, mode="all")
+    assert len(pairs) == V * (V - 1) // 2
+    i, j = pairs[:, 0], pairs[:, 1]
+    near = (j - i) <= 4
+    assert (inl[i[near], j[near]] > 300).all()         # every overlapping pair found its geometry
+    assert (inl[i[~near & (j - i > 5)], j[~near & (j - i > 5)]] < 30).all()
+    rng = np.random.default_rng(5)
+    sample = list(rng.permutation(np.flatnonzero(near))[:12]) + list(rng.permutation(np.flatnonzero(j - i > 5))[:8])
+    for p in sample:
+        a, b = int(i[p]), int(j[p])
+        m, c = oracle.knn_match(descs[a], descs[b], 2, nthreads=16, u8path=True)
+        g = m[oracle.ratio_test(m, c, 0.7), 0]
+        assert good[a, b] == len(g), (a, b)
+        p1 = kps[a][g["queryIdx"]].astype(np.float64)
+        p2 = kps[b][g["trainIdx"]].astype(np.float64)
+        r = oracle.ransac(p1, p2, synth.REF_K, model=0, prob=0.99, threshold=1.0, max_iters=1000)
+        assert inl[a, b] == (int(r["n_inliers"]) if r["ok"] else 0), (a, b)
