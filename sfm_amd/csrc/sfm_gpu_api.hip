@@ -1,6 +1,7 @@
 // C ABI of libsfm_gpu: context, image preparation, k-NN matching entry points.
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "ransac_dev.h"
@@ -205,9 +206,11 @@ static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
 // caller has made `device` current.
 constexpr int MAX_DEVICES = 64;
 void* g_scratch_ptr[MAX_DEVICES] = {};
+std::mutex g_scratch_mutex;  // contexts may be created from several host threads
 hipError_t resolve_scratch(int device, void** out)
 {
     if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[device]) {
         void* p = nullptr;
         const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
@@ -434,14 +437,21 @@ int sfm_gpu_knn_match_images_noalloc(sfm_gpu_ctx* ctx, const sfm_gpu_image* quer
     if (q.n == 0) return SFM_GPU_OK;
     if (!matches_dev || !counts_dev) return ctx->fail(SFM_GPU_ERR_ARG, "null output pointer");
     if (!ctx->static_scratch) return ctx->fail(SFM_GPU_ERR_HIP, "static working memory was not resolved");
-    const KnnPlan plan = plan_knn(q.n, t.n, 1, -1);
+    const KnnPlan plan = plan_knn(q.n, t.n, 1, ctx->knn_variant);
     const size_t records = (size_t)plan.n_splits * q.rows_alloc * REC_SUBS;
     if (q.n > NOALLOC_MAX_QUERY || records > NOALLOC_MAX_RECORDS)
         return ctx->fail(SFM_GPU_ERR_CAPACITY,
                          "sfm_gpu_knn_match_images_noalloc: %d query rows x %d train parts = %zu records exceed "
                          "the static working memory (at most %d query rows and %zu records of 16 bytes)",
                          q.n, plan.n_splits, records, NOALLOC_MAX_QUERY, NOALLOC_MAX_RECORDS);
+    // launches go to the context's device; the caller's current device is put back
+    int prev_dev = -1;
+    if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
     SFM_HIP(ctx, hipSetDevice(ctx->device));
+    struct Restore {
+        int d;
+        ~Restore() { if (d >= 0) (void)hipSetDevice(d); }
+    } restore{prev_dev == ctx->device ? -1 : prev_dev};
     unsigned char* base = (unsigned char*)ctx->static_scratch;
     const KnnWorkspace ws = {(uint4*)base, (int32_t*)(base + NOALLOC_REDO_OFF), (KnnJob*)(base + NOALLOC_JOB_OFF)};
     const KnnJob job = make_knn_job(q, t, ws, matches_dev, counts_dev);

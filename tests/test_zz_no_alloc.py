@@ -83,3 +83,35 @@ def test_noalloc_rejects_sizes_beyond_its_static_memory(gpu_ctx):
     assert b"static working memory" in gpu_ctx._L.sfm_gpu_last_error_string(gpu_ctx.handle)
     qi.close()
     ti.close()
+
+
+def test_noalloc_allocates_no_device_memory_on_a_fresh_context():
+    """A context that has never run anything (all its grow-only workspaces at zero
+    capacity) goes straight to the entry point: free device memory is the same
+    before and after, and the results are those of the allocating entry point
+    on another context."""
+    import torch
+    q, t, _ = synth.planted_pair(2100, 5000, 31, 32, 33)
+    other = matcher.Context(0)
+    qo, to = matcher.Image(other, q), matcher.Image(other, t)
+    want_m, want_c = matcher.knn_match_images(other, qo, to, 2)
+    fresh = matcher.Context(0)
+    qi, ti = matcher.Image(fresh, q), matcher.Image(fresh, t)   # images allocate; the call under test must not
+    m = torch.full((2100 * 2 * 4,), -7, dtype=torch.int32, device="cuda")
+    c = torch.full((2100,), -7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    fresh.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(2):
+        fresh.check(fresh._L.sfm_gpu_knn_match_images_noalloc(fresh.handle, qi.handle, ti.handle, 2,
+                                                              ctypes.c_void_p(m.data_ptr()),
+                                                              ctypes.c_void_p(c.data_ptr())))
+        fresh.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 == free0, "device memory changed by %d bytes" % (free0 - free1)
+    got_m = m.cpu().numpy().view(_lib.DMATCH_DTYPE).reshape(2100, 2)
+    assert got_m.tobytes() == want_m.tobytes() and (c.cpu().numpy() == want_c).all()
+    for im in (qi, ti, qo, to):
+        im.close()
+    fresh.close()
+    other.close()
