@@ -28,6 +28,12 @@
 // solves, the rotation of the absolute-orientation step by the polar
 // decomposition through a symmetric eigenproblem instead of a 3x3 SVD, and the
 // rotation vector from the matrix without cv::Rodrigues' orthonormalising SVD.
+// Two more places where this flow is known to differ from OpenCV's and a result
+// can move in its last digits: hypotheses are scored with the rotation matrix the
+// solver returned, where OpenCV projects with Rodrigues(Rodrigues(R)) of the
+// stored rotation vector; and when the final pose over all inliers cannot be
+// computed the best hypothesis is returned with success, where OpenCV returns
+// false.
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -412,7 +418,9 @@ int oracle_pnp_ransac(const double* object_pts, const double* image_pts, int n, 
     // through the normalised float32 value and back, as undistortPoints with no
     // distortion followed by the EPnP constructor does
     std::vector<float> of(3 * (size_t)n), uf(2 * (size_t)n);
-    std::vector<double> pw(3 * (size_t)n), us(2 * (size_t)n);
+    // ... while the final pose over all inliers comes from solvePnP on the float32
+    // pixels widened to double, whose undistortPoints keeps that depth: ur
+    std::vector<double> pw(3 * (size_t)n), us(2 * (size_t)n), ur(2 * (size_t)n);
     for (int i = 0; i < 3 * n; i++) { of[i] = (float)object_pts[i]; pw[i] = (double)of[i]; }
     for (int i = 0; i < n; i++) {
         uf[2 * i] = (float)image_pts[2 * i];
@@ -420,6 +428,8 @@ int oracle_pnp_ransac(const double* object_pts, const double* image_pts, int n, 
         const float xn = (float)(((double)uf[2 * i] - cam.uc) * ifx), yn = (float)(((double)uf[2 * i + 1] - cam.vc) * ify);
         us[2 * i] = (double)xn * cam.fu + cam.uc;
         us[2 * i + 1] = (double)yn * cam.fv + cam.vc;
+        ur[2 * i] = (((double)uf[2 * i] - cam.uc) * ifx) * cam.fu + cam.uc;
+        ur[2 * i + 1] = (((double)uf[2 * i + 1] - cam.vc) * ify) * cam.fv + cam.vc;
     }
     double R[9], t[3];
     auto finish = [&](const double* Rm, const double* tm) {
@@ -480,8 +490,8 @@ int oracle_pnp_ransac(const double* object_pts, const double* image_pts, int n, 
     for (int i = 0; i < n; i++)
         if (mask[i]) {
             ipw.insert(ipw.end(), &pw[3 * i], &pw[3 * i] + 3);
-            ius.push_back(us[2 * i]);
-            ius.push_back(us[2 * i + 1]);
+            ius.push_back(ur[2 * i]);
+            ius.push_back(ur[2 * i + 1]);
         }
     if (epnp(cam, ipw.data(), ius.data(), best, R, t)) finish(R, t);
     else finish(bestR, bestT);

@@ -417,11 +417,15 @@ __device__ void epnp_wave(const PnpCam cam, const double* __restrict__ pw, const
 
 // ---- kernels -------------------------------------------------------------------
 
-// Narrowing of both point sets to float32 and the solver's pixel coordinates
-// (through the normalised float32 value and back), as the OpenCV front end does.
+// Narrowing of both point sets to float32 and the solver's pixel coordinates, as
+// the OpenCV front end does: the hypotheses see them through the normalised
+// float32 value and back (us), the final pose over all inliers through a
+// normalisation kept in double (ur: solvePnP is handed the float32 pixels widened
+// to double there, and undistortPoints keeps its input's depth).
 __global__ void __launch_bounds__(256) pnp_prep_kernel(const double* __restrict__ obj, const double* __restrict__ img,
                                                        int n, PnpCam cam, double* __restrict__ pw,
-                                                       double* __restrict__ us, float* __restrict__ uf)
+                                                       double* __restrict__ us, float* __restrict__ uf,
+                                                       double* __restrict__ ur)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -433,6 +437,8 @@ __global__ void __launch_bounds__(256) pnp_prep_kernel(const double* __restrict_
     const float xn = (float)(((double)u - cam.uc) * ifx), yn = (float)(((double)v - cam.vc) * ify);
     us[2 * i] = (double)xn * cam.fu + cam.uc;
     us[2 * i + 1] = (double)yn * cam.fv + cam.vc;
+    ur[2 * i] = (((double)u - cam.uc) * ifx) * cam.fu + cam.uc;
+    ur[2 * i + 1] = (((double)v - cam.vc) * ify) * cam.fv + cam.vc;
 }
 
 // One workgroup of one wavefront per problem.  table != null: problem h is the
@@ -645,7 +651,7 @@ extern "C" int sfm_gpu_pnp_ransac(sfm_gpu_ctx* ctx, const double* object_pts, co
     const size_t pose_b = align256((size_t)(n_hyp + 1) * 13 * 8), cnt_b = align256((size_t)(n_hyp + 1) * 4 + 16);
     const size_t hyp_work = 32 + 7 * 5 + 5;  // doubles per hypothesis: gathered sample + solver scratch
     const size_t work_b = align256(std::max((size_t)n_hyp * hyp_work, (size_t)7 * n + 64) * 8);
-    const size_t total = in_b + 2 * (pw_b + us_b) + uf_b + mask_b + table_b + pose_b + cnt_b + work_b;
+    const size_t total = in_b + 2 * (pw_b + us_b) + us_b + uf_b + mask_b + table_b + pose_b + cnt_b + work_b;
     SFM_HIP(ctx, ctx->pnp_ws.reserve(total));
     char* base = ctx->pnp_ws.as<char>();
     double* d_obj = (double*)base;
@@ -655,7 +661,8 @@ extern "C" int sfm_gpu_pnp_ransac(sfm_gpu_ctx* ctx, const double* object_pts, co
     float* d_uf = (float*)((char*)d_us + us_b);
     double* d_ipw = (double*)((char*)d_uf + uf_b);
     double* d_ius = (double*)((char*)d_ipw + pw_b);
-    uint8_t* d_mask = (uint8_t*)((char*)d_ius + us_b);
+    double* d_ur = (double*)((char*)d_ius + us_b);
+    uint8_t* d_mask = (uint8_t*)((char*)d_ur + us_b);
     int32_t* d_table = (int32_t*)((char*)d_mask + mask_b);
     double* d_pose = (double*)((char*)d_table + table_b);
     int32_t* d_counts = (int32_t*)((char*)d_pose + pose_b);
@@ -667,7 +674,7 @@ extern "C" int sfm_gpu_pnp_ransac(sfm_gpu_ctx* ctx, const double* object_pts, co
     {
         ProfScope ps(ctx, "pnp_prep");
         hipLaunchKernelGGL(pnp_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_obj, d_img, n, cam, d_pw, d_us,
-                           d_uf);
+                           d_uf, d_ur);
         SFM_HIP(ctx, hipGetLastError());
     }
     const float thr = (float)(reprojection_error * reprojection_error);
@@ -735,7 +742,7 @@ extern "C" int sfm_gpu_pnp_ransac(sfm_gpu_ctx* ctx, const double* object_pts, co
         ProfScope ps(ctx, "pnp_score");
         hipLaunchKernelGGL(pnp_score_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, s, d_pw, d_uf, n, cam, d_pose, thr,
                            d_counts, d_mask, win);
-        hipLaunchKernelGGL(pnp_compact_kernel, dim3(1), dim3(1024), 0, s, d_mask, n, d_pw, d_us, d_ipw, d_ius, d_ninl);
+        hipLaunchKernelGGL(pnp_compact_kernel, dim3(1), dim3(1024), 0, s, d_mask, n, d_pw, d_ur, d_ipw, d_ius, d_ninl);
         SFM_HIP(ctx, hipGetLastError());
     }
     {
