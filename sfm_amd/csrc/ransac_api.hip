@@ -124,10 +124,14 @@ int fill_params(sfm_gpu_ctx* ctx, RansacProb& pb, const RansacParams& rp)
 // Runs RANSAC for n_prob problems whose descriptors (with every device pointer
 // set) are in `probs`.  `results` receives n_prob * R_COUNT ints.  On return
 // the masks and models are on the device; the stream has been synchronised.
+// optimistic (adaptive mode): only the first batch of sample rows is enqueued,
+// nothing is waited for, and `results` stays empty: a problem whose loop wants
+// more rows than that is left with R_STATE_DONE clear and R_OK zero, for the
+// caller to find and to run again without this flag.
 int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int hyp_cap,
                  const RansacParams& rp, const int32_t* custom_table_host, std::vector<int32_t>& results,
                  bool need_results, RansacProb* dprobs_ready = nullptr, bool points_ready = false,
-                 const PairDev* dpairs = nullptr, bool* pairs_done = nullptr)
+                 const PairDev* dpairs = nullptr, bool* pairs_done = nullptr, bool optimistic = false)
 {
     const int n_prob = (int)probs.size();
     const int m = probs[0].m;
@@ -191,25 +195,13 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
 
     // Adaptive mode: hypotheses are scored in batches on the GPU and OpenCV's
     // sequential loop (RANSACPointSetRegistrator::run) is replayed over the
-    // counts, which reproduces its order-dependent early termination exactly.
-    struct St {
-        int n = 0, niters = 0, iter = 0, best = 0, hyp = -1, q = -1;
-        bool done = false, direct = false, failed = false;
-    };
-    std::vector<St> st(n_prob);
+    // counts by ransac_replay_kernel, which reproduces its order-dependent early
+    // termination exactly.  Between batches the host only looks at the problems'
+    // result blocks: who is done, and how many more rows the others still want.
     const int max_it = std::max(rp.max_iters, 1);
-    int rc = 0;
-    // The point counts are only known on the device; they come back with the
-    // first batch's counts (the kernels themselves leave problems with n < m
-    // alone), which saves one round trip per call.
-    for (int p = 0; p < n_prob; ++p) st[p].niters = max_it;
-    std::vector<int32_t> counts;
     int done_rows = 0;
-    while (done_rows < max_it) {
-        int want = 0;
-        for (auto& t : st)
-            if (!t.done) want = std::max(want, t.niters - done_rows);
-        if (want <= 0) break;
+    int want = max_it;
+    while (done_rows < max_it && want > 0) {
         int b = done_rows == 0 ? 32 : 128;
         b = std::min(b, std::min(want, max_it - done_rows));
         {
@@ -225,90 +217,22 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             SFM_HIP(ctx, launch_ransac_score(s, dprobs, n_prob, cap, rp.model, done_rows, b, false, ctx->score_filter,
                                              ctx->score_prune));
         }
-        counts.resize((size_t)n_prob * b * 10);
-        // the problems' workspaces are carved at a constant stride: one strided copy
-        // brings every problem's slice of counts
-        bool uniform = n_prob > 1;
-        const ptrdiff_t stride = n_prob > 1 ? (const char*)probs[1].counts - (const char*)probs[0].counts : 0;
-        for (int p = 1; p < n_prob && uniform; ++p)
-            uniform = (const char*)probs[p].counts - (const char*)probs[p - 1].counts == stride && stride > 0;
-        SFM_HIP(ctx, ctx->pin_b.reserve(counts.size() * 4));
-        int32_t* counts_pin = ctx->pin_b.as<int32_t>();
-        if (uniform) {
-            SFM_HIP(ctx, hipMemcpy2DAsync(counts_pin, (size_t)b * 40, probs[0].counts + (size_t)done_rows * 10,
-                                          (size_t)stride, (size_t)b * 40, (size_t)n_prob, hipMemcpyDeviceToHost,
-                                          s));
-        } else {
-            for (int p = 0; p < n_prob; ++p) {
-                if (st[p].done) continue;
-                SFM_HIP(ctx, hipMemcpyAsync(&counts_pin[(size_t)p * b * 10],
-                                            probs[p].counts + (size_t)done_rows * 10, (size_t)b * 40,
-                                            hipMemcpyDeviceToHost, s));
-            }
-        }
-        rc = fetch_results();
-        if (rc) return rc;
-        std::memcpy(counts.data(), counts_pin, counts.size() * 4);
-        if (done_rows == 0)
-            for (int p = 0; p < n_prob; ++p) {
-                st[p].n = results[(size_t)p * R_COUNT + R_N];
-                if (st[p].n < m) { st[p].done = true; st[p].failed = true; }
-            }
-        for (int p = 0; p < n_prob; ++p) {
-            St& t = st[p];
-            if (t.done) continue;
-            const int valid = results[(size_t)p * R_COUNT + R_VALID];
-            t.direct = results[(size_t)p * R_COUNT + R_DIRECT] != 0;
-            if (t.direct) {
-                // n == m: one direct solve, every point an inlier
-                const int c0 = counts[(size_t)p * b * 10];
-                t.done = true;
-                t.failed = c0 < 0;
-                t.hyp = 0;
-                t.q = 0;
-                t.best = t.n;
-                t.iter = 0;
-                continue;
-            }
-            const int32_t* c = &counts[(size_t)p * b * 10];
-            for (; t.iter < t.niters && t.iter < done_rows + b; ++t.iter) {
-                if (t.iter >= valid) {  // getSubset failed
-                    if (t.iter == 0) t.failed = true;
-                    t.done = true;
-                    break;
-                }
-                const int32_t* row = c + (size_t)(t.iter - done_rows) * 10;
-                for (int q = 0; q < 10; ++q) {
-                    const int good = row[q];
-                    if (good < 0) continue;
-                    if (good > std::max(t.best, m - 1)) {
-                        t.best = good;
-                        t.hyp = t.iter;
-                        t.q = q;
-                        t.niters = update_num_iters(rp.prob, (double)(t.n - good) / t.n, m, t.niters);
-                    }
-                }
-            }
-            if (t.iter >= t.niters) t.done = true;
-        }
+        SFM_HIP(ctx, launch_ransac_replay(s, dprobs, n_prob, done_rows, b, max_it, rp.prob));
         done_rows += b;
+        if (optimistic) break;  // the caller looks at the states later
+        const int rc = fetch_results();
+        if (rc) return rc;
+        want = 0;
+        for (int p = 0; p < n_prob; ++p) {
+            const int32_t* r = &results[(size_t)p * R_COUNT];
+            if (!(r[R_STATE] & R_STATE_DONE)) want = std::max(want, r[R_NITERS] - done_rows);
+        }
     }
-    for (int p = 0; p < n_prob; ++p) {
-        St& t = st[p];
-        int32_t* r = &results[(size_t)p * R_COUNT];
-        const bool ok = !t.failed && t.best > 0 && t.hyp >= 0;
-        r[R_OK] = ok ? 1 : 0;
-        r[R_HYP] = ok ? t.hyp : -1;
-        r[R_Q] = ok ? t.q : -1;
-        r[R_NINL] = ok ? t.best : 0;
-        r[R_ITERS] = t.iter;
-    }
-    SFM_HIP(ctx, hipMemcpyAsync(probs[0].result, results.data(), (size_t)n_prob * R_COUNT * 4,
-                                hipMemcpyHostToDevice, s));
     {
         ProfScope ps(ctx, "ransac_mask");
         SFM_HIP(ctx, launch_ransac_mask(s, dprobs, n_prob, cap));
     }
+    if (optimistic) return SFM_GPU_OK;
     SFM_HIP(ctx, hipStreamSynchronize(s));
     return SFM_GPU_OK;
 }

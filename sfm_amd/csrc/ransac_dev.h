@@ -26,8 +26,12 @@ enum {
     R_S1 = 13,     // staged scoring: points [0, R_S1) are scored for every listed model first ...
     R_MID = 14,    // ... then [R_S1, R_MID) for what the first cut leaves, then the rest (multiples of 128, or n)
     R_S0 = 15,     // the opening stretch [0, R_S0) of the first stage, from which R_S1 is chosen
-    R_COUNT = 16
+    R_COUNT = 16,
+    // adaptive mode (the staged scoring of the fixed-count mode does not run there):
+    R_NITERS = R_S1,  // the loop bound as it stands, shrinking with every better model
+    R_STATE = R_MID   // R_STATE_* bits
 };
+enum { R_STATE_DONE = 1, R_STATE_FAILED = 2 };
 
 constexpr int MAX_MODELS = 10;  // candidate models per hypothesis (5-point: <= 10)
 
@@ -126,6 +130,12 @@ hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_pro
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
                                int n_hyp, bool staged, int filter_mode, int prune_mode);
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
+// Adaptive mode: replays RANSACPointSetRegistrator::run's loop over the counts of
+// sample rows [row0, row0 + nrows) on the device (one wavefront per problem); a
+// problem's progress lives in its result block (R_ITERS, R_NINL, R_HYP, R_Q,
+// R_NITERS, R_STATE), and R_OK is set once it is done.
+hipError_t launch_ransac_replay(hipStream_t s, const RansacProb* probs, int n_prob, int row0, int nrows, int max_iters,
+                                double confidence);
 
 // One image pair between the k-NN output and RANSAC (pair_kernels.hip).
 struct PairDev {

@@ -1970,6 +1970,99 @@ __global__ void __launch_bounds__(1024) ransac_select_kernel(const RansacProb* _
     if (pairs && tid == 0) report(running);
 }
 
+// cv::RANSACUpdateNumIters (OpenCV 4.5.5 calib3d ptsetreg.cpp), as the host's
+// update_num_iters spells it.
+__device__ int update_num_iters_dev(double p, double ep, int model_points, int max_iters)
+{
+    p = fmax(p, 0.);
+    p = fmin(p, 1.);
+    ep = fmax(ep, 0.);
+    ep = fmin(ep, 1.);
+    double num = fmax(1. - p, 2.2250738585072014e-308);
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < 2.2250738585072014e-308) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+// Adaptive mode.  The loop of RANSACPointSetRegistrator::run over the rows
+// [row0, row0 + nrows) whose candidate models have just been counted:
+//     for (iter = ...; iter < niters; iter++)
+//         for each model of the sample, in solver order:
+//             if (good > max(best, m - 1)) { take it; niters = RANSACUpdateNumIters(...); }
+// replayed in order by one lane, so that the order-dependent shrinking of niters
+// comes out as in the sequential program.  One wavefront per problem; the rows'
+// counts are brought into LDS by all lanes first.  Progress is parked in the
+// result block between launches (R_ITERS, R_NINL, R_HYP, R_Q, R_NITERS, R_STATE).
+constexpr int REPLAY_ROWS = 128;
+__global__ void __launch_bounds__(64) ransac_replay_kernel(const RansacProb* __restrict__ probs, int row0, int nrows,
+                                                           int max_iters, double confidence)
+{
+    __shared__ int32_t s_counts[REPLAY_ROWS * MAX_MODELS];
+    const RansacProb pb = probs[blockIdx.x];
+    const int lane = threadIdx.x;
+    int32_t* r = pb.result;
+    const int n = *pb.n_ptr, m = pb.m;
+    int state = row0 == 0 ? 0 : r[R_STATE];
+    if (row0 == 0 && n < m) state = R_STATE_DONE | R_STATE_FAILED;
+    if (row0 > 0 && (state & R_STATE_DONE)) return;
+    if (!(state & R_STATE_DONE))
+        for (int i = lane; i < nrows * MAX_MODELS; i += 64) s_counts[i] = pb.counts[(size_t)row0 * MAX_MODELS + i];
+    __syncthreads();
+    if (lane != 0) return;
+    int niters = row0 == 0 ? max_iters : r[R_NITERS];
+    int iter = row0 == 0 ? 0 : r[R_ITERS];
+    int best = row0 == 0 ? 0 : r[R_NINL];
+    int hyp = row0 == 0 ? -1 : r[R_HYP];
+    int q = row0 == 0 ? -1 : r[R_Q];
+    if (!(state & R_STATE_DONE)) {
+        const int valid = r[R_VALID];
+        if (r[R_DIRECT]) {
+            // n == m: one direct solve, every point an inlier
+            state = R_STATE_DONE | (s_counts[0] < 0 ? R_STATE_FAILED : 0);
+            hyp = 0;
+            q = 0;
+            best = n;
+            iter = 0;
+        } else {
+            for (; iter < niters && iter < row0 + nrows; ++iter) {
+                if (iter >= valid) {  // getSubset failed
+                    if (iter == 0) state |= R_STATE_FAILED;
+                    state |= R_STATE_DONE;
+                    break;
+                }
+                const int32_t* row = s_counts + (iter - row0) * MAX_MODELS;
+                for (int k = 0; k < MAX_MODELS; ++k) {
+                    const int good = row[k];
+                    if (good < 0) continue;
+                    if (good > max(best, m - 1)) {
+                        best = good;
+                        hyp = iter;
+                        q = k;
+                        niters = update_num_iters_dev(confidence, (double)(n - good) / n, m, niters);
+                    }
+                }
+            }
+            if (iter >= niters) state |= R_STATE_DONE;
+        }
+    }
+    if (state & R_STATE_DONE) {
+        const bool ok = !(state & R_STATE_FAILED) && best > 0 && hyp >= 0;
+        r[R_OK] = ok ? 1 : 0;
+        r[R_HYP] = ok ? hyp : -1;
+        r[R_Q] = ok ? q : -1;
+        r[R_NINL] = ok ? best : 0;
+    } else {
+        r[R_HYP] = hyp;
+        r[R_Q] = q;
+        r[R_NINL] = best;
+    }
+    r[R_ITERS] = iter;
+    r[R_NITERS] = niters;
+    r[R_STATE] = state;
+}
+
 // Inlier mask of the selected model (result[R_HYP], result[R_Q]) and a copy of
 // the model itself.  Leaves mask untouched when no model was found.
 __global__ void __launch_bounds__(256) ransac_mask_kernel(const RansacProb* __restrict__ probs)
@@ -2096,6 +2189,13 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
 hipError_t launch_ransac_select(hipStream_t s, const RansacProb* probs, int n_prob, int n_hyp, const PairDev* pairs)
 {
     hipLaunchKernelGGL(ransac_select_kernel, dim3(n_prob), dim3(1024), 0, s, probs, n_hyp, pairs);
+    return hipGetLastError();
+}
+hipError_t launch_ransac_replay(hipStream_t s, const RansacProb* probs, int n_prob, int row0, int nrows, int max_iters,
+                                double confidence)
+{
+    if (nrows > REPLAY_ROWS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ransac_replay_kernel, dim3(n_prob), dim3(64), 0, s, probs, row0, nrows, max_iters, confidence);
     return hipGetLastError();
 }
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap)
