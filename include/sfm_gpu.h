@@ -404,9 +404,12 @@ int sfm_gpu_match_pairs_pose(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int
  *
  *   sfm_gpu_match_pairs_begin  enqueues one batch (every pair must fit one
  *                     launch group: SFM_GPU_ERR_CAPACITY otherwise, as when two
- *                     batches are already in flight).  With mode FIXED it
- *                     returns without waiting for the device; ADAPTIVE needs the
- *                     host between its rounds and returns when they are done.
+ *                     batches are already in flight).  It returns without
+ *                     waiting for the device.  (With mode ADAPTIVE the loop's
+ *                     first 32 sample rows are enqueued, which is all it takes
+ *                     whenever the inlier share is above about 67 %, or below 5
+ *                     inliers; a batch in which some pair wants more is run
+ *                     again, waiting between the rounds, inside _end.)
  *                     The images must stay alive and unchanged until the
  *                     matching _end; other calls on the context may be made in
  *                     between (they queue behind the batch).

@@ -97,7 +97,9 @@ __global__ void __launch_bounds__(1024) ratio_compact_kernel(const PairDev* __re
     }
 }
 
-__global__ void __launch_bounds__(1024) inlier_compact_kernel(const PairDev* __restrict__ pairs)
+// check_state (adaptive RANSAC enqueued without waiting for its outcome): a pair
+// whose loop has not finished reports -1 inliers, and the caller runs it again.
+__global__ void __launch_bounds__(1024) inlier_compact_kernel(const PairDev* __restrict__ pairs, int check_state)
 {
     __shared__ int wsum[16];
     __shared__ int base;
@@ -105,6 +107,16 @@ __global__ void __launch_bounds__(1024) inlier_compact_kernel(const PairDev* __r
     if (threadIdx.x == 0) base = 0;
     __syncthreads();
     const int n = *pd.n_good;
+    if (check_state && !(pd.result[R_STATE] & R_STATE_DONE)) {
+        if (threadIdx.x == 0) {
+            *pd.n_inliers = 0;
+            if (pd.host_counts) {
+                pd.host_counts[0] = n;
+                pd.host_counts[1] = -1;
+            }
+        }
+        return;
+    }
     const bool ok = pd.result[R_OK] != 0;
     if (ok) {
         for (int start = 0; start < n; start += 1024) {
@@ -204,9 +216,9 @@ hipError_t launch_ratio_compact(hipStream_t s, const PairDev* pairs, int n_pairs
     return hipGetLastError();
 }
 
-hipError_t launch_inlier_compact(hipStream_t s, const PairDev* pairs, int n_pairs)
+hipError_t launch_inlier_compact(hipStream_t s, const PairDev* pairs, int n_pairs, bool check_state)
 {
-    hipLaunchKernelGGL(inlier_compact_kernel, dim3(n_pairs), dim3(1024), 0, s, pairs);
+    hipLaunchKernelGGL(inlier_compact_kernel, dim3(n_pairs), dim3(1024), 0, s, pairs, check_state ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -472,10 +472,15 @@ static int mp_reserve(sfm_gpu_ctx* ctx, const MpPlan& pl)
 // records_dev: caller-owned device memory for the inlier records (pair p's at
 // records_dev + p * match_capacity), or null: a buffer of the context when
 // want_inliers, none otherwise.
+// optimistic (adaptive RANSAC only): the first batch of sample rows is enqueued and
+// nothing is waited for; a pair whose loop is not over by then reports -1 inliers
+// in res_pinned and has to be run again without this flag.
 static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* images, const int32_t* pairs,
                       int g0, int g, const sfm_gpu_match_params* params, bool want_inliers, int match_capacity,
-                      std::vector<PairDev>& pds, void* res_pinned, sfm_gpu_dmatch* records_dev = nullptr)
+                      std::vector<PairDev>& pds, void* res_pinned, sfm_gpu_dmatch* records_dev = nullptr,
+                      bool optimistic = false, int records_g0 = -1)
 {
+    if (records_g0 < 0) records_g0 = g0;  // where the group's first pair sits in records_dev
     hipStream_t s = ctx->stream;
     std::vector<KnnJob> jobs(g);
     std::vector<RansacProb> probs(g, pl.proto);
@@ -513,7 +518,7 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
         pd.kp_t = t.kp;
         pd.good = (sfm_gpu_dmatch*)(ctx->mp_good.as<char>() + (pl.good_b + pl.inl_b) * i);
         pd.inliers = !want_inliers ? nullptr
-                     : records_dev ? records_dev + (size_t)(g0 + i) * match_capacity
+                     : records_dev ? records_dev + (size_t)(records_g0 + i) * match_capacity
                                    : (sfm_gpu_dmatch*)((char*)pd.good + pl.good_b);
         pd.px1 = (double*)(ctx->mp_pts.as<char>() + pl.px_b * 2 * i);
         pd.px2 = (double*)(ctx->mp_pts.as<char>() + pl.px_b * 2 * i + pl.px_b);
@@ -577,12 +582,13 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
         SFM_HIP(ctx, launch_ratio_compact(s, dpds, g, pl.nq_max, params->ratio));
     }
     bool pairs_done = false;  // fixed-count mode: the selection kernel has gathered the inliers too
+    const bool opt = optimistic && pl.rp.mode == SFM_GPU_RANSAC_ADAPTIVE;
     int rc = ransac_batch(ctx, probs, pl.nq_max, pl.hyp_cap, pl.rp, nullptr, results, false, dprobs, true, dpds,
-                          &pairs_done);
+                          &pairs_done, opt);
     if (rc) return rc;
     if (!pairs_done) {
         ProfScope ps(ctx, "inlier_compact");
-        SFM_HIP(ctx, launch_inlier_compact(s, dpds, g));
+        SFM_HIP(ctx, launch_inlier_compact(s, dpds, g, opt));
     }
     return SFM_GPU_OK;  // inlier_compact has written the counts into res_pinned
 }
@@ -643,28 +649,94 @@ static int match_pairs_impl(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int 
         per_pair2 = ransac_ws_bytes(pl.nq_max, hyp_cap2, proto2.m);
         SFM_HIP(ctx, ctx->rs_models2.reserve(per_pair2 * (size_t)pl.group + (size_t)R_COUNT * 4 * pl.group));
     }
-    SFM_HIP(ctx, ctx->mp_stage_sync.reserve(mp_stage_bytes(pl.group)));
-    SFM_HIP(ctx, ctx->mp_res_sync.reserve(8 * (size_t)pl.group));
-    std::vector<PairDev> pds;
-    for (int g0 = 0; g0 < n_pairs; g0 += pl.group) {
-        const int g = std::min(pl.group, n_pairs - g0);
-        ctx->up_stage = &ctx->mp_stage_sync;  // the previous group has been waited for
+    for (auto& slot : ctx->mp_sync) {
+        SFM_HIP(ctx, slot.stage.reserve(mp_stage_bytes(pl.group)));
+        SFM_HIP(ctx, slot.res.reserve(8 * (size_t)pl.group));
+        if (!slot.ev) SFM_HIP(ctx, hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
+        // the group's inlier records, when they are to be copied out behind a later group
+        if (inlier_matches && !pose)
+            SFM_HIP(ctx, slot.rec.reserve((size_t)pl.group * match_capacity * sizeof(sfm_gpu_dmatch)));
+    }
+    // Enqueues group k (pairs g0 ..) in slot k & 1.
+    auto enqueue = [&](int k, bool optimistic) -> int {
+        sfm_gpu_ctx::MpSlot& slot = ctx->mp_sync[k & 1];
+        const int g0 = k * pl.group, g = std::min(pl.group, n_pairs - g0);
+        ctx->up_stage = &slot.stage;  // this slot's previous group has been waited for
         ctx->up_used = 0;
-        rc = mp_enqueue(ctx, pl, images, pairs, g0, g, params, want_records, match_capacity, pds,
-                        ctx->mp_res_sync.p);
+        sfm_gpu_dmatch* rec = inlier_matches && !pose ? slot.rec.as<sfm_gpu_dmatch>() : nullptr;
+        const int rc2 = mp_enqueue(ctx, pl, images, pairs, g0, g, params, want_records, match_capacity, slot.pds,
+                                   slot.res.p, rec, optimistic, 0);
         ctx->up_stage = nullptr;
-        if (rc) return rc;
-        SFM_HIP(ctx, hipStreamSynchronize(s));
-        mp_collect(ctx, ctx->mp_res_sync.as<int32_t>(), g, n_good + g0, n_inliers + g0);
+        if (rc2) return rc2;
+        SFM_HIP(ctx, hipEventRecord(slot.ev, s));
+        slot.n_pairs = g;
+        return SFM_GPU_OK;
+    };
+    // Waits for group k and hands its results to the caller.  *again = true (and
+    // nothing handed over) when a pair's adaptive loop wanted more sample rows than
+    // the optimistic enqueue gave it.
+    auto collect = [&](int k, bool* again) -> int {
+        sfm_gpu_ctx::MpSlot& slot = ctx->mp_sync[k & 1];
+        const int g0 = k * pl.group, g = slot.n_pairs;
+        SFM_HIP(ctx, hipEventSynchronize(slot.ev));
+        const int32_t* res = slot.res.as<int32_t>();
+        if (again) {
+            *again = false;
+            for (int i = 0; i < g; ++i)
+                if (res[2 * i + 1] < 0) *again = true;
+            if (*again) return SFM_GPU_OK;
+        }
+        mp_collect(ctx, res, g, n_good + g0, n_inliers + g0);
         if (inlier_matches) {
             for (int i = 0; i < g; ++i)
                 if (n_inliers[g0 + i] > 0)
                     SFM_HIP(ctx, hipMemcpyAsync(inlier_matches + (size_t)(g0 + i) * match_capacity,
-                                                pds[i].inliers, (size_t)n_inliers[g0 + i] * sizeof(sfm_gpu_dmatch),
+                                                slot.pds[i].inliers, (size_t)n_inliers[g0 + i] * sizeof(sfm_gpu_dmatch),
                                                 hipMemcpyDeviceToHost, s));
-            SFM_HIP(ctx, hipStreamSynchronize(s));
+            if (pose) SFM_HIP(ctx, hipStreamSynchronize(s));
         }
-        if (pose) {
+        return SFM_GPU_OK;
+    };
+    const int n_groups = (n_pairs + pl.group - 1) / pl.group;
+    if (!pose) {
+        // Two groups on the stream: group k+1 is enqueued before the host waits for
+        // group k, so the device does not idle through the host's work between
+        // groups.  The adaptive loop is enqueued optimistically (its first batch of
+        // sample rows, which is all it needs on image pairs that overlap or plainly
+        // do not); a group in which some pair wants more is run again, in the blocking
+        // way, once the stream has drained -- by then the group behind it is complete
+        // and everything it produced sits in its own slot.
+        for (int k = 0; k <= n_groups; ++k) {
+            if (k < n_groups) {
+                rc = enqueue(k, true);
+                if (rc) return rc;
+            }
+            if (k == 0) continue;
+            bool again = false;
+            rc = collect(k - 1, &again);
+            if (rc) return rc;
+            if (again) {
+                SFM_HIP(ctx, hipStreamSynchronize(s));
+                rc = enqueue(k - 1, false);
+                if (rc) return rc;
+                rc = collect(k - 1, nullptr);
+                if (rc) return rc;
+                // (the shared workspaces now hold group k-1 again; group k, which ran in
+                // between, is complete, and pairs of it that want more rows are found when
+                // it is collected, as usual)
+            }
+        }
+        if (inlier_matches) SFM_HIP(ctx, hipStreamSynchronize(s));  // the last records are on the host
+        return SFM_GPU_OK;
+    }
+    for (int k = 0; k < n_groups; ++k) {
+        const int g0 = k * pl.group, g = std::min(pl.group, n_pairs - g0);
+        rc = enqueue(k, false);
+        if (rc) return rc;
+        rc = collect(k, nullptr);
+        if (rc) return rc;
+        std::vector<PairDev>& pds = ctx->mp_sync[k & 1].pds;
+        {
             // main.cpp:400-420 for every pair: a second essential-matrix RANSAC over the
             // pair's selectMatches, then recoverPose with that matrix on all of them.
             // The group's pair descriptors are still on the device (pds[0].prob points
@@ -762,11 +834,19 @@ static int match_pairs_begin_impl(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images
     ctx->up_stage = &slot.stage;  // this slot's previous batch has been ended
     ctx->up_used = 0;
     rc = mp_enqueue(ctx, pl, images, pairs, 0, n_pairs, params, records_dev != nullptr, match_capacity, pds,
-                    slot.res.p, records_dev);
+                    slot.res.p, records_dev, true);
     ctx->up_stage = nullptr;
     if (rc) return rc;
     SFM_HIP(ctx, hipEventRecord(slot.ev, ctx->stream));
     slot.rec_pending = false;
+    // kept for _end: an adaptive batch in which some pair wants more sample rows than
+    // the first batch of them is run again there
+    slot.images.assign(images, images + n_images);
+    slot.pairs.assign(pairs, pairs + 2 * (size_t)n_pairs);
+    slot.params = *params;
+    slot.records_dev = records_dev;
+    slot.records_host_dev = host_dev;
+    slot.match_capacity = match_capacity;
     if (records_host) {
         // behind the batch, on a stream of its own: the next batch starts on the
         // context's stream while these records travel.  The counts are read from
@@ -822,10 +902,36 @@ int sfm_gpu_match_pairs_end(sfm_gpu_ctx* ctx, int32_t* n_good, int32_t* n_inlier
     if (capacity < slot.n_pairs)
         return ctx->fail(SFM_GPU_ERR_CAPACITY, "the oldest batch has %d pairs, room for %d", slot.n_pairs, capacity);
     SFM_HIP(ctx, hipEventSynchronize(slot.ev));
-    if (slot.rec_pending) {
-        SFM_HIP(ctx, hipEventSynchronize(slot.rec_ev));
-        slot.rec_pending = false;
+    if (slot.rec_pending) SFM_HIP(ctx, hipEventSynchronize(slot.rec_ev));
+    bool again = false;
+    for (int i = 0; i < slot.n_pairs; ++i)
+        if (slot.res.as<int32_t>()[2 * i + 1] < 0) again = true;
+    if (again) {
+        // Some pair's adaptive loop was not over after the rows enqueued by _begin:
+        // the batch runs again, this time waiting between the batches of rows.  A
+        // younger batch in flight finishes first (the workspaces are shared); what
+        // it produced sits in its own slot and in the caller's memory.
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MpPlan pl;
+        const bool rec = slot.records_dev != nullptr;
+        int rc = mp_plan(ctx, pl, slot.images.data(), (int)slot.images.size(), slot.pairs.data(), slot.n_pairs,
+                         &slot.params, rec, slot.match_capacity, false);
+        if (rc) return rc;
+        rc = mp_reserve(ctx, pl);
+        if (rc) return rc;
+        std::vector<PairDev> pds;
+        ctx->up_stage = &slot.stage;
+        ctx->up_used = 0;
+        rc = mp_enqueue(ctx, pl, slot.images.data(), slot.pairs.data(), 0, slot.n_pairs, &slot.params, rec,
+                        slot.match_capacity, pds, slot.res.p, slot.records_dev, false);
+        ctx->up_stage = nullptr;
+        if (rc) return rc;
+        if (slot.records_host_dev)
+            SFM_HIP(ctx, launch_records_to_host(ctx->stream, slot.records_dev, slot.records_host_dev,
+                                                (size_t)slot.match_capacity, slot.res.as<int32_t>(), slot.n_pairs));
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    slot.rec_pending = false;
     --ctx->mp_outstanding;
     mp_collect(ctx, slot.res.as<int32_t>(), slot.n_pairs, n_good, n_inliers);
     return SFM_GPU_OK;

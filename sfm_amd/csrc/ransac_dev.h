@@ -161,7 +161,8 @@ hipError_t launch_ratio_compact(hipStream_t s, const PairDev* pairs, int n_pairs
 // dst and src_pinned are 16-byte aligned and padded to a multiple of 16 bytes
 hipError_t launch_upload_block(hipStream_t s, void* dst, const void* src_pinned, size_t bytes, int32_t* redo,
                                size_t redo_stride, int n_jobs);
-hipError_t launch_inlier_compact(hipStream_t s, const PairDev* pairs, int n_pairs);
+// check_state: pairs whose adaptive loop is not finished report -1 inliers instead
+hipError_t launch_inlier_compact(hipStream_t s, const PairDev* pairs, int n_pairs, bool check_state = false);
 // pair p's first counts[2p+1] records from src + p*stride to dst_pinned + p*stride (device-visible host memory)
 hipError_t launch_records_to_host(hipStream_t s, const sfm_gpu_dmatch* src, sfm_gpu_dmatch* dst_pinned, size_t stride,
                                   const int32_t* counts, int n_pairs);

@@ -8,6 +8,10 @@
 #include <map>
 #include <string>
 
+#include <vector>
+
+#include "sfm_gpu.h"
+#include "ransac_dev.h"
 #include "sfm_internal.h"
 
 namespace sfm {
@@ -176,11 +180,23 @@ struct sfm_gpu_ctx {
         bool rec_pending = false;
         sfm::PinnedBuf stage, res;
         int n_pairs = 0;
+        // what it takes to run the batch again (adaptive RANSAC enqueued without
+        // waiting: a pair whose loop wants more sample rows than the first batch)
+        std::vector<sfm_gpu_image*> images;
+        std::vector<int32_t> pairs;
+        sfm_gpu_match_params params;
+        sfm_gpu_dmatch* records_dev = nullptr;
+        sfm_gpu_dmatch* records_host_dev = nullptr;
+        int match_capacity = 0;
+        // sfm_gpu_match_pairs' own groups: device addresses of the group's pairs, and
+        // the group's inlier records when the caller wants them on the host
+        std::vector<sfm::PairDev> pds;
+        sfm::DevBuf rec;
     };
     MpSlot mp_slot[2];
     int mp_next = 0;         // slot the next begin takes
     int mp_outstanding = 0;  // begun and not yet ended (the oldest is mp_next - mp_outstanding)
-    sfm::PinnedBuf mp_stage_sync, mp_res_sync;
+    MpSlot mp_sync[2];       // sfm_gpu_match_pairs keeps two of its launch groups on the stream
     // side stream on which a batch's inlier records travel to the host while the
     // next batch already runs on `stream` (created on first use)
     hipStream_t rec_stream = nullptr;

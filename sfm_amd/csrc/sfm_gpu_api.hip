@@ -292,8 +292,12 @@ void sfm_gpu_destroy(sfm_gpu_ctx* c)
     c->tmp_t.release();
     c->pin_a.release();
     c->pin_b.release();
-    c->mp_stage_sync.release();
-    c->mp_res_sync.release();
+    for (auto& slot : c->mp_sync) {
+        if (slot.ev) (void)hipEventDestroy(slot.ev);
+        slot.stage.release();
+        slot.res.release();
+        slot.rec.release();
+    }
     if (c->front_ev) (void)hipEventDestroy(c->front_ev);
     for (auto& u : c->up_ring) {
         if (u.ev) (void)hipEventDestroy(u.ev);

@@ -480,3 +480,71 @@ def test_begin_end_leaves_each_pairs_select_matches_on_device_and_host(gpu_ctx, 
     assert e.value.code == _lib.ERR_CAPACITY
     for im in images:
         im.close()
+
+
+def test_adaptive_groups_in_flight_with_pairs_that_want_more_sample_rows(gpu_ctx, oracle):
+    """sfm_gpu_match_pairs keeps two launch groups on the stream and enqueues the
+    adaptive loop's first batch of sample rows without waiting; pairs whose loop
+    wants more (low inlier share: hundreds of iterations) make their group run
+    again.  261 pairs = two groups, a mix of overlapping pairs (done in the
+    first batch), pairs with about half their matches wrong (more batches) and
+    pairs with nothing in common: counts and records equal one-pair calls, and
+    the oracle pipeline on a sample."""
+    rng = np.random.default_rng(77)
+    n_img = 14
+    descs = [synth.sift_like(700 + 31 * v, 900 + v) for v in range(n_img)]
+    kps = [np.stack([rng.uniform(0, synth.IMG_W, len(d)), rng.uniform(0, synth.IMG_H, len(d))], 1).astype(np.float32)
+           for d in descs]
+    # image v+1 repeats 200 rows of image v; half of those keep a random keypoint (wrong geometry)
+    for v in range(n_img - 1):
+        rq, rt = 40 * (v % 3) + np.arange(200), 300 + np.arange(200)
+        descs[v + 1][rt] = np.clip(descs[v][rq] + np.rint(rng.normal(0, 5, (200, 128))), 0, 255).astype(np.float32)
+        planted = np.full(len(descs[v]), -1, np.int64)
+        planted[rq] = rt
+        kq, kt = synth.keypoints_for_pair(len(descs[v]), len(descs[v + 1]), planted, 40 + v,
+                                          wrong_frac=0.5 if v % 2 else 0.05)
+        kps[v][rq] = kq[rq]
+        kps[v + 1][rt] = kt[rt]
+    images = [matcher.Image(gpu_ctx, d, k) for d, k in zip(descs, kps)]
+    all_pairs = [[i, j] for i in range(n_img) for j in range(n_img) if i != j]
+    pairs = np.array((all_pairs * 2)[:261], np.int32)
+    kw = dict(ratio=0.8, model=matcher.MODEL_ESSENTIAL, mode=matcher.RANSAC_ADAPTIVE, prob=0.99, threshold=1.0,
+              max_iters=400)
+    ng, ni, sel = matcher.match_pairs(gpu_ctx, images, pairs, synth.REF_K, want_matches=True, **kw)
+    ng2, ni2 = matcher.match_pairs(gpu_ctx, images, pairs, synth.REF_K, **kw)          # counts only
+    assert (ng2 == ng).all() and (ni2 == ni).all()
+    checked = 0
+    for p in list(range(0, 261, 9)) + [255, 256, 260]:
+        i, j = pairs[p]
+        g1, i1, s1 = matcher.match_pairs(gpu_ctx, images, pairs[p:p + 1], synth.REF_K, want_matches=True, **kw)
+        assert g1[0] == ng[p] and i1[0] == ni[p] and s1[0].tobytes() == sel[p].tobytes()
+        if j == i + 1:
+            og, osel = _oracle_pair(oracle, descs[i], descs[j], kps[i], kps[j], synth.REF_K, 0.8, 0, prob=0.99,
+                                    threshold=1.0, max_iters=400)
+            assert og == ng[p] and osel.tobytes() == sel[p].tobytes()
+            checked += 1
+    assert checked >= 2 and (ni > 60).sum() >= 13
+    # the same through begin / end with two batches in flight, the older one needing the second pass
+    pa, pb = pairs[:40], pairs[40:70]
+    cap = max(len(d) for d in descs)
+    import torch
+    from sfm_amd import _lib
+    dev = [torch.full((len(pl_), cap, 4), -7, dtype=torch.int32, device="cuda") for pl_ in (pa, pb)]
+    host = [torch.full((len(pl_), cap, 4), -9, dtype=torch.int32).pin_memory() for pl_ in (pa, pb)]
+    torch.cuda.synchronize()
+    ba = matcher.PairBatch(gpu_ctx, images, pa, synth.REF_K, records_dev=dev[0].data_ptr(), match_capacity=cap,
+                           records_host=host[0].data_ptr(), **kw)
+    bb = matcher.PairBatch(gpu_ctx, images, pb, synth.REF_K, records_dev=dev[1].data_ptr(), match_capacity=cap,
+                           records_host=host[1].data_ptr(), **kw)
+    for rep in range(2):
+        ba.begin()
+        bb.begin()
+        for b_, lo, hi, h, d in ((ba, 0, 40, host[0], dev[0]), (bb, 40, 70, host[1], dev[1])):
+            g, c = b_.end()
+            assert (g == ng[lo:hi]).all() and (c == ni[lo:hi]).all()
+            hh = h.numpy().view(_lib.DMATCH_DTYPE).reshape(hi - lo, cap)
+            dd = d.cpu().numpy().view(_lib.DMATCH_DTYPE).reshape(hi - lo, cap)
+            for p in range(hi - lo):
+                assert hh[p, :c[p]].tobytes() == sel[lo + p].tobytes() == dd[p, :c[p]].tobytes()
+    for im in images:
+        im.close()
