@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--prep-stream", type=int, default=1, choices=[0, 1],
                     help="1: descriptor conversion of the next step on a side stream, beside the current step's "
                          "RANSAC (never beside a sweep); 0: everything on one stream")
+    ap.add_argument("--main-priority", type=int, default=0,
+                    help="HIP priority of the stream the matching runs on (-1: above the conversion's side stream)")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip the two-stream reference measurement after the timed region")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
@@ -306,7 +308,7 @@ def main():
     row_bytes = 128 * (1 if args.desc_u8 else 4)  # densely packed rows
     desc_dtype = matcher.DESC_U8 if args.desc_u8 else matcher.DESC_F32
     pairs = np.array([[2 * p, 2 * p + 1] for p in range(B)], np.int32)
-    stream = torch.cuda.Stream()
+    stream = torch.cuda.Stream(priority=args.main_priority)
     # One input set per entry of --wrong-fracs: different pairs (other seeds) with
     # that share of geometrically wrong matches.  Set 0 is also the CPU leg's.
     inputs = []

@@ -75,8 +75,11 @@ int sfm_gpu_debug_set_score_filter(sfm_gpu_ctx* ctx, int on);
  * the points and, between stages, drops the models that provably cannot reach
  * the best count (their entries in the dumped counts stay partial, never above
  * the true count).  0 switches the pruning off so that every dumped count is
- * complete; 1 (default) on; 2 on, but never more than one cut.  The selected
- * model, its inlier count and the mask are the same in every mode. */
+ * complete; 1 (default) on: the list ordered by the counts of an opening
+ * stretch, wavefronts of like models that stop once none can reach the bound;
+ * 2 and 3: the earlier schedule of two stages sized from that stretch, with two
+ * cuts or one.  The selected model, its inlier count and the mask are the same
+ * in every mode. */
 int sfm_gpu_debug_set_score_prune(sfm_gpu_ctx* ctx, int on);
 
 /* Vote counts of the four pose candidates in the last sfm_gpu_recover_pose call

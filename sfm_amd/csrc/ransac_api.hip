@@ -56,7 +56,7 @@ size_t ransac_ws_bytes(int cap, int hyp_cap, int m)
     b += align_up((size_t)hyp_cap * 90 * 8, 256);        // models
     b += align_up((size_t)hyp_cap * 4, 256);             // nmodels
     b += align_up((size_t)hyp_cap * 10 * 4, 256);        // counts
-    b += align_up((size_t)hyp_cap * 10 * 4, 256);        // list
+    b += align_up((size_t)hyp_cap * 10 * 4, 256) * 2;    // list, list2
     b += align_up((size_t)cap, 256);                     // mask
     b += 256;                                            // model_out
     return b;
@@ -76,6 +76,7 @@ void carve_ransac(RansacProb& pb, char* base, int cap, int hyp_cap, int m)
     pb.nmodels = (int32_t*)take((size_t)hyp_cap * 4);
     pb.counts = (int32_t*)take((size_t)hyp_cap * 10 * 4);
     pb.list = (int32_t*)take((size_t)hyp_cap * 10 * 4);
+    pb.list2 = (int32_t*)take((size_t)hyp_cap * 10 * 4);
     pb.mask = (uint8_t*)take((size_t)cap);
     pb.model_out = (double*)take(256);
 }
@@ -257,7 +258,7 @@ int sfm_gpu_debug_set_score_filter(sfm_gpu_ctx* ctx, int on)
 int sfm_gpu_debug_set_score_prune(sfm_gpu_ctx* ctx, int on)
 {
     if (!ctx) return SFM_GPU_ERR_ARG;
-    if (on < 0 || on > 2) return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "score prune mode %d", on);
+    if (on < 0 || on > 4) return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "score prune mode %d", on);
     ctx->score_prune = on;
     return SFM_GPU_OK;
 }

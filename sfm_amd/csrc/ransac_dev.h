@@ -23,10 +23,13 @@ enum {
     R_NLIST = 10,  // candidate models listed for the batch being scored
     R_MAXABS = 11, // largest |coordinate| of the problem's points, float32 bits
     R_BOUND = 12,  // largest complete inlier count known so far in the batch being scored
-    R_S1 = 13,     // staged scoring: points [0, R_S1) are scored for every listed model first ...
-    R_MID = 14,    // ... then [R_S1, R_MID) for what the first cut leaves, then the rest (multiples of 128, or n)
-    R_S0 = 15,     // the opening stretch [0, R_S0) of the first stage, from which R_S1 is chosen
-    R_COUNT = 16,
+    R_S1 = 13,     // staged scoring: end of the stage that follows the opening stretch (a multiple of 128, or n)
+    R_MID = 14,    // place of a further cut between R_S1 and n (a multiple of 128, or n)
+    R_S0 = 15,     // the opening stretch [0, R_S0): every listed model is counted there before anything is planned
+    R_S3 = 16,     // a third cut between R_MID and n
+    R_LIVE = 17,   // R_LIVE + k, k = 0..4: leading groups of 64 of the ordered list in which some model could
+                   // still reach the bound when stage k of the scoring began (an upper bound; stage k writes k + 1)
+    R_COUNT = 24,
     // adaptive mode (the staged scoring of the fixed-count mode does not run there):
     R_NITERS = R_S1,  // the loop bound as it stands, shrinking with every better model
     R_STATE = R_MID   // R_STATE_* bits
@@ -49,6 +52,7 @@ struct RansacProb {
     int32_t* nmodels;      // [hyp_cap]
     int32_t* counts;       // [hyp_cap][MAX_MODELS], -1 = no such model
     int32_t* list;         // [hyp_cap * MAX_MODELS] dense list of hyp*MAX_MODELS + q of one batch
+    int32_t* list2;        // [hyp_cap * MAX_MODELS] where the list is put in order (ransac_sortplan_kernel)
     int32_t* result;       // [R_COUNT]
     uint8_t* mask;         // [cap]
     double* model_out;     // [9]
@@ -119,14 +123,16 @@ hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int
 hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp,
                                int gen_rows = 0);
 // staged (fixed-count mode): every model is scored on an opening stretch of the
-// points, whose best partial count tells each problem how many outliers to
-// expect; the first stage is extended to outnumber them, the models that provably
-// cannot reach the best count are dropped (their counts stay partial) and the rest
-// go on, with a second cut further in.  All sizes are chosen per problem on the
-// device.  The selected model, its count and the mask are those of staged = false.
+// points; the list is then ordered by those counts, its best few are completed
+// (the largest of their counts bounds the winner's from below), and the rest runs
+// on in pieces, a wavefront of models stopping once none of them can reach the
+// bound (their counts stay partial); what is left is compacted and finished.  All
+// sizes are chosen per problem on the device.  The selected model, its count and
+// the mask are those of staged = false.
 // filter_mode: 1 = float32 filter with a rigorous bound in front of the double
 // precision test, 0 = double precision only (same counts).  prune_mode: 0 = never
-// drop a model, 1 = as described above, 2 = at most one cut.
+// drop a model, 1 = as described above, 2 / 3 = the earlier schedule (two stages sized from the
+// opening stretch's best count, two cuts / one cut).
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
                                int n_hyp, bool staged, int filter_mode, int prune_mode);
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap);

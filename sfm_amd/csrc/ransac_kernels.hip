@@ -1586,84 +1586,74 @@ __device__ __forceinline__ f2v filter_h_out(const PairTerms& t, const FilterCons
     return fma2(t.n, splat(fc.c3), fma2(t.den, splat(-fc.c4), splat(-fc.kout[0])));
 }
 
-// Inlier counts: one thread per listed candidate model, which it keeps in
-// registers; the points of the chunk are the same for every lane and are read
-// through scalar loads (nothing writes them while this kernel runs), so a
-// point costs each model nothing but its own arithmetic.
-// grid = (groups of 64 models, point chunks from chunk0 on, problems); a
-// workgroup strides over further groups / chunks when the grid is smaller than
-// the work, keeping its models in registers from chunk to chunk.
-constexpr int SCORE_WAVES = 1;  // independent wavefronts per workgroup
-// The points a launch covers are [result[slot_begin], min(n, result[slot_end])) of
-// its problem (a slot < 0 stands for 0 / n), the models the first
-// min(R_NLIST, list_limit) of the list.
-template <int MODEL, bool STRIDED>
-__global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const RansacProb* __restrict__ probs, int chunk_pts_arg,
-                                                          int use_filter, int slot_begin, int slot_end,
-                                                          int list_limit)
+// One lane's model during scoring: float32 copies of its coefficients and the
+// constants of the float32 filter.  The double-precision coefficients stay in
+// memory and are fetched again for the few tests that need them, which keeps the
+// scoring loops at a register count that lets six or more wavefronts share a
+// SIMD.
+template <int MODEL>
+struct ScoreLane {
+    const double* Mg;
+    float Mf[9];
+    FilterConst fc;
+    __device__ __forceinline__ void load(const RansacProb& pb, int e, float R)
+    {
+        Mg = pb.models + (size_t)(e / MAX_MODELS) * 90 + (e % MAX_MODELS) * 9;
+        double M[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) M[i] = Mg[i];
+        fc = make_filter<MODEL>(M, (double)R, pb.tf);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Mf[k] = (float)M[k];
+    }
+};
+
+constexpr int SCORE_QCAP = 40;  // tests a lane can park per span before it falls back to exact evaluation on the spot
+
+// Inliers of the lane's model among the points [i0, i1) of the problem (i0 a
+// multiple of 4).  The points are the same for every lane and arrive by scalar
+// loads (nothing writes them while a scoring kernel runs), so a point costs each
+// model nothing but its own arithmetic.  Tests the filter cannot settle are
+// parked per lane (`parked`: SCORE_QCAP x 64 offsets of this wavefront in LDS)
+// and redone in double precision after the span, so that one lane's doubt does
+// not make the other 63 wait at every such point.
+template <int MODEL>
+__device__ __forceinline__ int score_span(const RansacProb& pb, const ScoreLane<MODEL>& m, int i0, int i1,
+                                          unsigned short* parked, int lane, int use_filter)
 {
     typedef const double __attribute__((address_space(4))) cdouble;
     typedef const f2v __attribute__((address_space(4))) cf2v;
-    const RansacProb pb = probs[blockIdx.z];
-    const int nlist = min(__builtin_amdgcn_readfirstlane(pb.result[R_NLIST]), list_limit);
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (((int)blockIdx.x * SCORE_WAVES + wv) * 64 >= nlist) return;
-    const int pts_begin = slot_begin >= 0 ? __builtin_amdgcn_readfirstlane(pb.result[slot_begin]) : 0;
-    int n = __builtin_amdgcn_readfirstlane(*pb.n_ptr);
-    if (slot_end >= 0) n = min(n, __builtin_amdgcn_readfirstlane(pb.result[slot_end]));
-    // chunk_pts_arg <= 0: the problem's stretch in equal pieces, one per grid row
-    const int chunk_pts = chunk_pts_arg > 0 ? chunk_pts_arg
-                                            : (((max(n - pts_begin, 0) + (int)gridDim.y - 1) / (int)gridDim.y + 3) & ~3);
-    if (pts_begin + (int)blockIdx.y * chunk_pts >= n) return;  // stage boundaries and chunk_pts are multiples of 4
-    const int lane = threadIdx.x & 63;
-    constexpr int QCAP = 40;
-    __shared__ unsigned short parked_all[SCORE_WAVES * QCAP * 64];
-    unsigned short* parked = parked_all + wv * (QCAP * 64);
-    for (int g0 = (blockIdx.x * SCORE_WAVES + wv) * 64; g0 < nlist; g0 += gridDim.x * SCORE_WAVES * 64) {
-    const bool active = g0 + lane < nlist;
-    const int e = pb.list[active ? g0 + lane : g0];
-    const double* Mg = pb.models + (size_t)(e / MAX_MODELS) * 90 + (e % MAX_MODELS) * 9;
-    double M[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) M[i] = Mg[i];
+    typedef const float __attribute__((address_space(4))) cfloat;
     const float tf = pb.tf;
     const double tlo = pb.tlo, thi = pb.thi;
     cdouble* X1 = (cdouble*)(uintptr_t)pb.x1;
     cdouble* X2 = (cdouble*)(uintptr_t)pb.x2;
-    auto exact = [&](int i) -> int {
+    cfloat* S = (cfloat*)(uintptr_t)pb.soa;
+    auto exact = [&](const double* M, int i) -> int {
         if (MODEL == SFM_GPU_MODEL_ESSENTIAL)
             return sampson_inlier_u(M, X1[2 * i], X1[2 * i + 1], X2[2 * i], X2[2 * i + 1], tf, tlo, thi);
         return symepi_inlier_u(M, X1[2 * i], X1[2 * i + 1], X2[2 * i], X2[2 * i + 1], tf, tlo, thi);
     };
     int cnt = 0;
-    const float R = __int_as_float(__builtin_amdgcn_readfirstlane(pb.result[R_MAXABS]));
-    const FilterConst fc = make_filter<MODEL>(M, (double)R, tf);
-    float Mf[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Mf[k] = (float)M[k];
-    typedef const float __attribute__((address_space(4))) cfloat;
-    cfloat* S = (cfloat*)(uintptr_t)pb.soa;
-    for (int i0 = pts_begin + blockIdx.y * chunk_pts; i0 < n; i0 += gridDim.y * chunk_pts) {
-    const int i1 = min(n, i0 + chunk_pts);
     int i = i0;
-    // Tests the filter cannot settle are parked per lane (offset within the
-    // chunk) and redone in double precision after the sweep, so that one
-    // lane's doubt does not make the other 63 wait at every such point.
     int n_parked = 0;
     if (use_filter) {
         auto park = [&](int idx) {
 #ifdef SFM_GPU_TIMING_BUILD
             if (use_filter >= 2) return;  // timing experiments: unsettled tests are dropped (wrong counts)
 #endif
-            if (n_parked < QCAP) {
+            if (n_parked < SCORE_QCAP) {
                 parked[n_parked * 64 + lane] = (unsigned short)(idx - i0);
                 ++n_parked;
             } else {
-                cnt += exact(idx);
+                double M[9];  // rare: the lane's queue is full
+#pragma unroll
+                for (int k = 0; k < 9; ++k) M[k] = m.Mg[k];
+                cnt += exact(M, idx);
             }
         };
         // four points per step (one 64-byte block: X1[4] Y1[4] X2[4] Y2[4]), the
-        // next four already on their way; i0 is a multiple of 4
+        // next four already on their way
         const int i4 = i0 + ((i1 - i0) & ~3);
         f2v nx[8];
         auto fetch = [&](int at) {
@@ -1677,14 +1667,14 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
 #pragma unroll
             for (int k = 0; k < 8; ++k) cur[k] = nx[k];
             fetch(i + 4 < i4 ? i + 4 : i);  // the last step re-reads its own points
-            const PairTerms tA = filter_terms<MODEL>(Mf, cur[0], cur[2], cur[4], cur[6]);
-            const PairTerms tB = filter_terms<MODEL>(Mf, cur[1], cur[3], cur[5], cur[7]);
-            const f2v hinA = filter_h_in(tA, fc), hinB = filter_h_in(tB, fc);
+            const PairTerms tA = filter_terms<MODEL>(m.Mf, cur[0], cur[2], cur[4], cur[6]);
+            const PairTerms tB = filter_terms<MODEL>(m.Mf, cur[1], cur[3], cur[5], cur[7]);
+            const f2v hinA = filter_h_in(tA, m.fc), hinB = filter_h_in(tB, m.fc);
             const bool in0 = hinA.x <= 0.f, in1 = hinA.y <= 0.f, in2 = hinB.x <= 0.f, in3 = hinB.y <= 0.f;
             cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0) + (in2 ? 1 : 0) + (in3 ? 1 : 0);
             // the outlier test is only needed where a lane could not prove "in"
             if (__builtin_amdgcn_ballot_w64(!(in0 && in1 && in2 && in3)) != 0ull) {
-                const f2v houtA = filter_h_out(tA, fc), houtB = filter_h_out(tB, fc);
+                const f2v houtA = filter_h_out(tA, m.fc), houtB = filter_h_out(tB, m.fc);
                 const bool u0 = !(in0 || houtA.x >= 0.f), u1 = !(in1 || houtA.y >= 0.f);
                 const bool u2 = !(in2 || houtB.x >= 0.f), u3 = !(in3 || houtB.y >= 0.f);
                 if (u0 || u1 || u2 || u3) {
@@ -1696,13 +1686,346 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
             }
         }
     }
-    for (; i < i1; ++i) cnt += exact(i);
-    for (int k = 0; k < n_parked; ++k) cnt += exact(i0 + (int)parked[k * 64 + lane]);
-    if (!STRIDED) break;  // the grid covers every chunk: straight-line code
-    }  // chunks
-    if (active && cnt != 0) atomicAdd(&pb.counts[e], cnt);
-    if (!STRIDED) break;
-    }  // groups
+    // whatever is left needs the double-precision coefficients
+    if (__builtin_amdgcn_ballot_w64(i < i1 || n_parked > 0) != 0ull) {
+        double M[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) M[k] = m.Mg[k];
+        for (; i < i1; ++i) cnt += exact(M, i);
+        for (int k = 0; k < n_parked; ++k) cnt += exact(M, i0 + (int)parked[k * 64 + lane]);
+    }
+    return cnt;
+}
+
+// Inlier counts: one thread per listed candidate model, which it keeps in
+// registers (score_span).
+// grid = (groups of 64 models, point chunks from chunk0 on, problems); a
+// workgroup strides over further groups / chunks when the grid is smaller than
+// the work, keeping its models in registers from chunk to chunk.
+constexpr int SCORE_WAVES = 1;  // independent wavefronts per workgroup
+// The points a launch covers are [result[slot_begin], min(n, result[slot_end])) of
+// its problem (a slot < 0 stands for 0 / n), the models the first
+// min(R_NLIST, list_limit) of the list.
+// live_slot >= 0 (not with STRIDED): the launch is a stage over a list put in
+// order by ransac_sortplan_kernel.  A wavefront whose models have all fallen out
+// of reach of the bound R_BOUND (count so far + points left < bound: they can
+// neither win nor tie) stops at once; result[live_slot] bounds the groups that
+// can hold anything else, and the wavefronts that go on record the same for the
+// next stage in result[live_slot + 1].  The pieces of a stretch are then at
+// least SCORE_MIN_PIECE points long.
+constexpr int SCORE_MIN_PIECE = 128;
+template <int MODEL, bool STRIDED>
+__global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const RansacProb* __restrict__ probs, int chunk_pts_arg,
+                                                          int use_filter, int slot_begin, int slot_end,
+                                                          int list_limit, int live_slot)
+{
+    // live_slot >= 0: grid = (problems, pieces, groups), so that the groups at the head of the
+    // ordered list, the only ones with work in the later stages, are dispatched first and spread
+    // over the whole chip (consecutive workgroups are placed on the same compute unit until it
+    // is full: live groups side by side in the grid would share a few units while the rest idle)
+    const bool by_group = !STRIDED && live_slot >= 0;
+    const unsigned bx = by_group ? blockIdx.z : blockIdx.x, by = blockIdx.y, bz = by_group ? blockIdx.x : blockIdx.z;
+    const unsigned gdx = by_group ? gridDim.z : gridDim.x;
+    const RansacProb pb = probs[bz];
+    const int nlist = min(__builtin_amdgcn_readfirstlane(pb.result[R_NLIST]), list_limit);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (((int)bx * SCORE_WAVES + wv) * 64 >= nlist) return;
+    if (!STRIDED && live_slot >= 0 &&
+        (int)bx * SCORE_WAVES + wv >= __builtin_amdgcn_readfirstlane(pb.result[live_slot]))
+        return;
+    const int pts_begin = slot_begin >= 0 ? __builtin_amdgcn_readfirstlane(pb.result[slot_begin]) : 0;
+    const int n_all = __builtin_amdgcn_readfirstlane(*pb.n_ptr);
+    int n = n_all;
+    if (slot_end >= 0) n = min(n, __builtin_amdgcn_readfirstlane(pb.result[slot_end]));
+    // chunk_pts_arg <= 0: the problem's stretch in equal pieces, one per grid row
+    int chunk_pts = chunk_pts_arg > 0 ? chunk_pts_arg
+                                      : (((max(n - pts_begin, 0) + (int)gridDim.y - 1) / (int)gridDim.y + 3) & ~3);
+    if (!STRIDED && live_slot >= 0) chunk_pts = max(chunk_pts, SCORE_MIN_PIECE);
+    if (pts_begin + (int)by * chunk_pts >= n) return;  // stage boundaries and chunk_pts are multiples of 4
+    const int lane = threadIdx.x & 63;
+    __shared__ unsigned short parked_all[SCORE_WAVES * SCORE_QCAP * 64];
+    unsigned short* parked = parked_all + wv * (SCORE_QCAP * 64);
+    const float R = __int_as_float(__builtin_amdgcn_readfirstlane(pb.result[R_MAXABS]));
+    for (int g0 = (bx * SCORE_WAVES + wv) * 64; g0 < nlist; g0 += gdx * SCORE_WAVES * 64) {
+        const bool active = g0 + lane < nlist;
+        const int e = pb.list[active ? g0 + lane : g0];
+        if (!STRIDED && live_slot >= 0) {
+            // (every piece of the group sees the same counts: the stage before is complete)
+            const int bound = __builtin_amdgcn_readfirstlane(pb.result[R_BOUND]);
+            const bool alive = active && pb.counts[e] + (n_all - pts_begin) >= bound;
+            if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
+            if (by == 0 && lane == 0) atomicMax(&pb.result[live_slot + 1], g0 / 64 + 1);
+        }
+        ScoreLane<MODEL> m;
+        m.load(pb, e, R);
+        int cnt = 0;
+        for (int i0 = pts_begin + by * chunk_pts; i0 < n; i0 += gridDim.y * chunk_pts) {
+            cnt += score_span<MODEL>(pb, m, i0, min(n, i0 + chunk_pts), parked, lane, use_filter);
+            if (!STRIDED) break;  // the grid covers every chunk: straight-line code
+        }
+        if (active && cnt != 0) atomicAdd(&pb.counts[e], cnt);
+        if (!STRIDED) break;
+    }
+}
+
+// Sequential scoring with cuts: a wavefront takes 64 consecutive models of the
+// list (ordered by ransac_sortplan_kernel so that neighbours are of like quality)
+// through the points [R_S0, R_S1) in pieces of SEQ_PIECE, and after every piece
+// drops out once none of its models can still reach the bound B = R_BOUND
+// (count so far + points left < B: such a model can neither win nor tie).  The
+// first top_groups groups of the list, which mostly live to the end, are instead
+// scored over the whole stretch in `pieces` equal parts by one wavefront each,
+// without cuts.  grid = (problems, items): the long items of every problem are
+// dispatched first.
+constexpr int SEQ_PIECE = 128;
+template <int MODEL>
+__global__ void __launch_bounds__(64) ransac_score_seq_kernel(const RansacProb* __restrict__ probs, int use_filter,
+                                                              int top_groups, int pieces)
+{
+    __shared__ unsigned short parked[SCORE_QCAP * 64];
+    const RansacProb pb = probs[blockIdx.x];
+    const int nlist = __builtin_amdgcn_readfirstlane(pb.result[R_NLIST]);
+    const int n = __builtin_amdgcn_readfirstlane(*pb.n_ptr);
+    const int s0 = __builtin_amdgcn_readfirstlane(pb.result[R_S0]);
+    const int s1 = min(n, __builtin_amdgcn_readfirstlane(pb.result[R_S1]));
+    if (s0 >= s1) return;
+    const int item = blockIdx.y;
+    const int groups = (nlist + 63) / 64;
+    const int top = min(top_groups, groups);
+    int group, i_begin = s0, i_end = s1;
+    const bool seq = item >= top_groups * pieces;
+    if (seq) {
+        group = top + (item - top_groups * pieces);
+    } else {
+        group = item / pieces;
+        if (group >= top) return;
+        const int len = (((s1 - s0) + pieces - 1) / pieces + 3) & ~3;
+        i_begin = s0 + (item % pieces) * len;
+        i_end = min(s1, i_begin + len);
+    }
+    if (group >= groups || i_begin >= i_end) return;
+    const int lane = threadIdx.x;
+    const bool active = group * 64 + lane < nlist;
+    const int e = pb.list[active ? group * 64 + lane : group * 64];
+    const float R = __int_as_float(__builtin_amdgcn_readfirstlane(pb.result[R_MAXABS]));
+    if (!seq) {
+        ScoreLane<MODEL> m;
+        m.load(pb, e, R);
+        const int cnt = score_span<MODEL>(pb, m, i_begin, i_end, parked, lane, use_filter);
+        if (active && cnt != 0) atomicAdd(&pb.counts[e], cnt);
+        return;
+    }
+    const int bound = __builtin_amdgcn_readfirstlane(pb.result[R_BOUND]);
+    const int cnt0 = pb.counts[e];  // over [0, s0): nobody else touches this model's count during this launch
+    // many wavefronts hold nothing but models the opening stretch has already ruled out
+    if (__builtin_amdgcn_ballot_w64(active && cnt0 + (n - i_begin) >= bound) == 0ull) return;
+    int cnt = cnt0;
+    for (int i0 = i_begin; i0 < i_end; i0 += SEQ_PIECE) {
+        const int i1 = min(i_end, i0 + SEQ_PIECE);
+        // The model is set up anew for every piece (a few per cent of a piece's work):
+        // kept across the loop, its coefficients and filter constants add to the registers
+        // of the double-precision tests and halve the wavefronts a SIMD can hold.
+        int ee = e;
+        asm volatile("" : "+v"(ee));
+        ScoreLane<MODEL> m;
+        m.load(pb, ee, R);
+        cnt += score_span<MODEL>(pb, m, i0, i1, parked, lane, use_filter);
+        const bool alive = active && cnt + (n - i1) >= bound;
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
+    }
+    if (active) pb.counts[e] = cnt;
+}
+
+// Between the opening stretch [0, R_S0), on which every listed model has been
+// counted, and the sequential stage.  One workgroup per problem:
+//  * orders the list by descending partial count (counting sort; the order
+//    inside a bucket is whatever the atomics make it: only cost depends on it),
+//  * completes the SORT_TOP best of them over all remaining points and takes
+//    them off the list: the largest of their counts is the bound B (R_BOUND),
+//    a lower bound of the winner's count,
+//  * sets the end R_S1 of the sequential stage: far enough for a model that
+//    misses nearly every point to be dropped (it is dropped once its misses
+//    exceed n - B), at least SEQ_MIN points.
+constexpr int SORT_TOP = 8;
+constexpr int SEQ_MIN = 1024;
+
+// Entries base + tid + 1024 k (k < 8) of a problem's list and their counts, all
+// loads of one kind issued together: these one-workgroup kernels are chains of
+// dependent memory round trips, and a loop of load -> load -> use pays two of
+// them per turn.
+__device__ __forceinline__ void load_entries8(const RansacProb& pb, int base, int nlist, int tid, int (&e)[8],
+                                              int (&c)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int p = base + tid + 1024 * k;
+        e[k] = p < nlist ? pb.list[p] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] = e[k] >= 0 ? pb.counts[e[k]] : 0;
+}
+
+// Inliers of model M among the points first, first + stride, ... < n, by the
+// procedure of the mask, four points' loads in flight at a time.
+__device__ __forceinline__ int count_exact_strided(const RansacProb& pb, const double* M, int first, int stride, int n)
+{
+    int add = 0;
+    for (int i = first; i < n; i += 4 * stride) {
+        if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
+            double2 a[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ii = min(i + k * stride, n - 1);
+                a[k] = *(const double2*)(pb.x1 + 2 * ii);
+                b[k] = *(const double2*)(pb.x2 + 2 * ii);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i + k * stride < n) add += sampson_inlier(M, a[k].x, a[k].y, b[k].x, b[k].y, pb.tf, pb.tlo, pb.thi);
+        } else {
+            float2 a[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ii = min(i + k * stride, n - 1);
+                a[k] = *(const float2*)(pb.f1 + 2 * ii);
+                b[k] = *(const float2*)(pb.f2 + 2 * ii);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i + k * stride < n) add += symepi_inlier(M, a[k].x, a[k].y, b[k].x, b[k].y, pb.tf, pb.tlo, pb.thi);
+        }
+    }
+    return add;
+}
+
+__global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb* __restrict__ probs, int sequential)
+{
+    __shared__ int hist[SCORE_OPENING + 1];
+    __shared__ int s_add[SORT_TOP];
+    const RansacProb pb = probs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int n = *pb.n_ptr;
+    const int nlist = pb.result[R_NLIST];
+    const int bound0 = pb.result[R_BOUND];
+    const int s0 = min(n, SCORE_OPENING);
+    if (tid == 0) {
+        pb.result[R_S0] = s0;
+        pb.result[R_S1] = n;
+        pb.result[R_MID] = n;
+        pb.result[R_S3] = n;
+        for (int k = 0; k < 5; ++k) pb.result[R_LIVE + k] = 0;
+    }
+    if (nlist <= 0 || s0 >= n) return;
+    for (int b = tid; b <= SCORE_OPENING; b += 1024) hist[b] = 0;
+    if (tid < SORT_TOP) s_add[tid] = 0;
+    __syncthreads();
+    int e[8], c[8];  // the first 8192 entries stay in registers for the second pass
+    for (int base = 0; base < nlist; base += 8192) {
+        int eb[8], cb[8];
+        load_entries8(pb, base, nlist, tid, eb, cb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            cb[k] = min(max(cb[k], 0), SCORE_OPENING);
+            if (eb[k] >= 0) atomicAdd(&hist[cb[k]], 1);
+            if (base == 0) {
+                e[k] = eb[k];
+                c[k] = cb[k];
+            }
+        }
+    }
+    __syncthreads();
+    // hist[c] := first slot of bucket c, buckets in descending order of c
+    if (tid < 64) {
+        int running = 0;
+        for (int c0 = SCORE_OPENING; c0 >= 0; c0 -= 64) {
+            const int cc = c0 - tid;
+            const int v = cc >= 0 ? hist[cc] : 0;
+            int incl = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off);
+                if (tid >= off) incl += o;
+            }
+            if (cc >= 0) hist[cc] = running + incl - v;
+            running += __shfl(incl, 63);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (e[k] >= 0) pb.list2[atomicAdd(&hist[c[k]], 1)] = e[k];
+    for (int base = 8192; base < nlist; base += 8192) {
+        int eb[8], cb[8];
+        load_entries8(pb, base, nlist, tid, eb, cb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (eb[k] >= 0) pb.list2[atomicAdd(&hist[min(max(cb[k], 0), SCORE_OPENING)], 1)] = eb[k];
+    }
+    __syncthreads();
+    // the best SORT_TOP, 128 threads each, over the points the opening has not seen
+    const int top = min(SORT_TOP, nlist);
+    {
+        const int t = tid >> 7, j = tid & 127;
+        int add = 0;
+        if (t < top) {
+            const int et = pb.list2[t];
+            const double* Mg = pb.models + (size_t)(et / MAX_MODELS) * 90 + (et % MAX_MODELS) * 9;
+            double M[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) M[i] = Mg[i];
+            add = count_exact_strided(pb, M, s0 + j, 128, n);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) add += __shfl_xor(add, off);
+        if ((tid & 63) == 0 && t < top && add) atomicAdd(&s_add[t], add);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        int full = 0;
+        if (tid < top) {
+            const int et = pb.list2[tid];
+            full = pb.counts[et] + s_add[tid];
+            pb.counts[et] = full;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) full = max(full, __shfl_xor(full, off));
+        if (tid == 0) {
+            const int bound = max(bound0, full);
+            pb.result[R_BOUND] = bound;
+            pb.result[R_NLIST] = nlist - top;
+            pb.result[R_LIVE] = (nlist - top + 63) / 64;
+            auto up128 = [](int v) { return (v + 127) / 128 * 128; };
+            if (sequential) {
+                int s1 = s0 + up128(max(SEQ_MIN, (int)(1.5 * (double)(n - bound))));
+                if (n - s1 < 256) s1 = n;  // not worth another stage
+                pb.result[R_S1] = s1;
+            } else {
+                // A model that misses nearly every point falls out of reach once its misses
+                // exceed n - bound: the first stage ends just past that, where most of the
+                // list stops; the later stages grow, as fewer and fewer models reach them.
+                const int b1 = max(up128((int)(1.06 * (double)(n - bound)) + 16), s0 + 128);
+                const int b2 = b1 + up128(max(256, (n - b1) / 8));
+                const int b3 = b2 + up128(max(640, (n - b2) / 3));
+                pb.result[R_S1] = n - b1 < 256 ? n : b1;
+                pb.result[R_MID] = n - b2 < 256 ? n : b2;
+                pb.result[R_S3] = n - b3 < 256 ? n : b3;
+            }
+        }
+    }
+    // the rest of the ordered list becomes the list
+    for (int base = 0; base < nlist - top; base += 8192) {
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = base + tid + 1024 * k;
+            v[k] = p < nlist - top ? pb.list2[top + p] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = base + tid + 1024 * k;
+            if (p < nlist - top) pb.list[p] = v[k];
+        }
+    }
 }
 
 // Staged scoring, after every listed model has been scored on the opening stretch
@@ -1767,13 +2090,27 @@ __global__ void __launch_bounds__(1024) ransac_prune_kernel(const RansacProb* __
     const int n = *pb.n_ptr;
     const int nlist = pb.result[R_NLIST];
     const int pts_done = pb.result[slot_done];
+    const int bound0 = pb.result[R_BOUND];
     if (pts_done >= n || nlist <= 0) return;
-    // the listed model with the largest partial count
+    // the listed model with the largest partial count (the first 8192 entries and
+    // their counts stay in registers for the compaction)
+    int e[8], c[8];
     unsigned long long best = 0;
-    for (int p = tid; p < nlist; p += 1024) {
-        const unsigned c = (unsigned)pb.counts[pb.list[p]];
-        const unsigned long long key = ((unsigned long long)c << 32) | (0xFFFFFFFFu - (unsigned)p);
-        best = key > best ? key : best;
+    for (int base = 0; base < nlist; base += 8192) {
+        int eb[8], cb[8];
+        load_entries8(pb, base, nlist, tid, eb, cb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (eb[k] >= 0) {
+                const unsigned long long key =
+                    ((unsigned long long)(unsigned)cb[k] << 32) | (0xFFFFFFFFu - (unsigned)(base + tid + 1024 * k));
+                best = key > best ? key : best;
+            }
+            if (base == 0) {
+                e[k] = eb[k];
+                c[k] = cb[k];
+            }
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1785,22 +2122,14 @@ __global__ void __launch_bounds__(1024) ransac_prune_kernel(const RansacProb* __
     best = sh[0];
     for (int w = 1; w < 16; ++w) best = sh[w] > best ? sh[w] : best;
     const int pos = (int)(0xFFFFFFFFu - (unsigned)best);
-    const int e = pb.list[pos];
+    const int ebest = pb.list[pos];
     // its count over the remaining points, by the procedure of the mask
     {
-        const double* Mg = pb.models + (size_t)(e / MAX_MODELS) * 90 + (e % MAX_MODELS) * 9;
+        const double* Mg = pb.models + (size_t)(ebest / MAX_MODELS) * 90 + (ebest % MAX_MODELS) * 9;
         double M[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) M[i] = Mg[i];
-        int add = 0;
-        for (int i = pts_done + tid; i < n; i += 1024) {
-            if (pb.model == SFM_GPU_MODEL_ESSENTIAL)
-                add += sampson_inlier(M, pb.x1[2 * i], pb.x1[2 * i + 1], pb.x2[2 * i], pb.x2[2 * i + 1], pb.tf,
-                                      pb.tlo, pb.thi);
-            else
-                add += symepi_inlier(M, pb.f1[2 * i], pb.f1[2 * i + 1], pb.f2[2 * i], pb.f2[2 * i + 1], pb.tf,
-                                     pb.tlo, pb.thi);
-        }
+        int add = count_exact_strided(pb, M, pts_done + tid, 1024, n);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) add += __shfl_xor(add, off);
         if (lane == 0) wsum[wv] = add;
@@ -1809,8 +2138,8 @@ __global__ void __launch_bounds__(1024) ransac_prune_kernel(const RansacProb* __
             int tot = 0;
             for (int w = 0; w < 16; ++w) tot += wsum[w];
             const int full = (int)(best >> 32) + tot;
-            pb.counts[e] = full;
-            const int b = max(pb.result[R_BOUND], full);
+            pb.counts[ebest] = full;
+            const int b = max(bound0, full);
             pb.result[R_BOUND] = b;
             s_bound = b;
             s_pos = pos;
@@ -1825,8 +2154,21 @@ __global__ void __launch_bounds__(1024) ransac_prune_kernel(const RansacProb* __
         const int p = p0 + tid;
         int ent = -1;
         if (p < nlist && p != done_pos) {
-            const int le = pb.list[p];
-            if (pb.counts[le] + rest >= bound) ent = le;
+            int le, lc;
+            if (p0 < 8192) {  // tile p0 / 1024 of the registers (the loop is unrolled over the first eight tiles)
+                le = e[0];
+                lc = c[0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k)
+                    if (p0 == 1024 * k) {
+                        le = e[k];
+                        lc = c[k];
+                    }
+            } else {
+                le = pb.list[p];
+                lc = pb.counts[le];
+            }
+            if (lc + rest >= bound) ent = le;
         }
         const int keep = ent >= 0 ? 1 : 0;
         int incl = keep;
@@ -2134,47 +2476,77 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     const unsigned groups = (unsigned)(((size_t)n_hyp * maxm + 63) / 64);
     // strided: the grid is smaller than the work and its workgroups loop
     auto score = [&](int chunk_pts, int slot_begin, int slot_end, int chunks, unsigned gx, int list_limit,
-                     bool strided) {
-        const dim3 grid((gx + SCORE_WAVES - 1) / SCORE_WAVES, chunks, n_prob), block(SCORE_WAVES * 64);
+                     bool strided, int live_slot = -1) {
+        const unsigned gw = (gx + SCORE_WAVES - 1) / SCORE_WAVES;
+        const dim3 grid = live_slot >= 0 ? dim3(n_prob, chunks, gw) : dim3(gw, chunks, n_prob);
+        const dim3 block(SCORE_WAVES * 64);
         const int f = filter_mode;
         if (model == SFM_GPU_MODEL_ESSENTIAL) {
             if (strided)
                 hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL, true>), grid, block, 0, s, probs,
-                                   chunk_pts, f, slot_begin, slot_end, list_limit);
+                                   chunk_pts, f, slot_begin, slot_end, list_limit, live_slot);
             else
                 hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_ESSENTIAL, false>), grid, block, 0, s, probs,
-                                   chunk_pts, f, slot_begin, slot_end, list_limit);
+                                   chunk_pts, f, slot_begin, slot_end, list_limit, live_slot);
         } else {
             if (strided)
                 hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL, true>), grid, block, 0, s, probs,
-                                   chunk_pts, f, slot_begin, slot_end, list_limit);
+                                   chunk_pts, f, slot_begin, slot_end, list_limit, live_slot);
             else
                 hipLaunchKernelGGL((ransac_score_kernel<SFM_GPU_MODEL_FUNDAMENTAL, false>), grid, block, 0, s, probs,
-                                   chunk_pts, f, slot_begin, slot_end, list_limit);
+                                   chunk_pts, f, slot_begin, slot_end, list_limit, live_slot);
         }
     };
-    // Stages with a pruning step between them.  Every model runs over an opening
-    // stretch, from which each problem estimates its outliers
-    // (ransac_plan_kernel); the first stage is extended to outnumber them, the
-    // bound drops what cannot win, and the survivors -- still of mixed quality,
-    // anything above roughly half the winner's inlier rate -- are cut a second
-    // time further in; by then only models close to the winner remain.  The
-    // stage boundaries live in the problems' result blocks; a launch only fixes
-    // how far its grid reaches.
-    if (staged && prune_mode && cap >= 1024) {
+    // Stages with cuts.  Every model runs over an opening stretch; the list is
+    // then put in order of the counts there and its best few are completed: their
+    // largest count is the bound a model has to be able to reach.  Four stages
+    // follow, their ends chosen per problem from that bound
+    // (ransac_sortplan_kernel).  Nothing is compacted between them: in the ordered
+    // list the models that have fallen out of reach sit together, so whole
+    // wavefronts of them stop at the door, and a count of the leading groups
+    // still in play keeps most of those from looking at their models at all.
+    if (staged && prune_mode == 1 && cap >= 1024) {
+        score(SCORE_OPENING / 2, -1, R_S0, 2, groups, INT_MAX, false);
+        hipLaunchKernelGGL(ransac_sortplan_kernel, dim3(n_prob), dim3(1024), 0, s, probs, 0);
+        // pieces per stage: what a stage of the largest problem needs at 128 points a piece
+        const int p1 = std::max(1, std::min(8, cap / 4 / 128)), p4 = std::max(1, std::min(16, cap / 512));
+        score(0, R_S0, R_S1, p1, groups, INT_MAX, false, R_LIVE);
+        score(0, R_S1, R_MID, std::max(2, p4 / 8), groups, INT_MAX, false, R_LIVE + 1);
+        score(0, R_MID, R_S3, std::max(4, p4 / 4), groups, INT_MAX, false, R_LIVE + 2);
+        score(0, R_S3, -1, p4, groups, INT_MAX, false, R_LIVE + 3);
+    } else if (staged && prune_mode == 4 && cap >= 1024) {
+        // Kept for comparison: after the ordering, one stage of sequential pieces in which a
+        // wavefront of models stops as soon as none of them can reach the bound any more
+        // (ransac_score_seq_kernel), a compaction with a renewed bound, and the rest.
+        score(SCORE_OPENING, -1, R_S0, 1, groups, INT_MAX, false);
+        hipLaunchKernelGGL(ransac_sortplan_kernel, dim3(n_prob), dim3(1024), 0, s, probs, 1);
+        const int top_groups = std::max(1, std::min(8, (int)groups / 8)), pieces = 4;
+        const dim3 grid_seq(n_prob, top_groups * pieces + (groups > (unsigned)top_groups ? groups - top_groups : 0));
+        if (model == SFM_GPU_MODEL_ESSENTIAL)
+            hipLaunchKernelGGL((ransac_score_seq_kernel<SFM_GPU_MODEL_ESSENTIAL>), grid_seq, dim3(64), 0, s, probs,
+                               filter_mode, top_groups, pieces);
+        else
+            hipLaunchKernelGGL((ransac_score_seq_kernel<SFM_GPU_MODEL_FUNDAMENTAL>), grid_seq, dim3(64), 0, s, probs,
+                               filter_mode, top_groups, pieces);
+        hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, (int)R_S1);
+        const int depth = std::max(1, std::min(32, cap / 1024));
+        score(128, R_S1, -1, std::min(32, 2 * depth), (groups + 15) / 16, INT_MAX, true);
+    } else if (staged && prune_mode >= 2 && cap >= 1024) {
+        // The earlier schedule, kept for comparison: stages sized from the opening
+        // stretch's best count, a cut between them (prune_mode 2: two cuts, 3: one).
         score(SCORE_OPENING, -1, R_S0, 1, groups, INT_MAX, false);
         // the first stage may take up to a quarter of the capacity: with the ratio
         // test leaving well under half of the queries, that covers outlier shares
         // up to about one half, beyond which the bound has nothing to drop anyway
         const int cover = std::max(2 * SCORE_OPENING, (cap / 4 + 255) / 256 * 256);
-        hipLaunchKernelGGL(ransac_plan_kernel, dim3(n_prob), dim3(1024), 0, s, probs, cover, prune_mode == 2 ? 1 : 0);
+        hipLaunchKernelGGL(ransac_plan_kernel, dim3(n_prob), dim3(1024), 0, s, probs, cover, prune_mode == 3 ? 1 : 0);
         score(0, R_S0, R_S1, SCORE_SPLIT, groups, INT_MAX, false);
         hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, (int)R_S1);
         // the survivors are few: pieces of 128 points, and a grid an eighth of
         // the list wide (a sixteenth after the second cut) that strides over
         // whatever is left
         const int depth = std::max(1, std::min(32, cap / 1024));
-        if (prune_mode == 1) {
+        if (prune_mode == 2) {
             score(128, R_S1, R_MID, depth, (groups + 7) / 8, INT_MAX, true);
             hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, (int)R_MID);
             score(128, R_MID, -1, std::min(32, 2 * depth), (groups + 15) / 16, INT_MAX, true);

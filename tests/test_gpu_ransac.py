@@ -213,26 +213,31 @@ def test_scoring_filter_is_exact_on_near_threshold_points(gpu_ctx, oracle, full_
     assert 1500 + 200 < best < 6000 - 200
 
 
+@pytest.mark.parametrize("prune_mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("model", [0, 1])
 @pytest.mark.parametrize("seed,n,frac", [(31, 400, 0.9), (32, 513, 0.5), (33, 3300, 0.93), (34, 3300, 0.35),
-                                         (35, 14000, 0.8), (36, 5000, 0.05)])
-def test_pruned_scoring_selects_the_same_model(gpu_ctx, oracle, model, seed, n, frac):
-    """Default fixed-count scoring (staged, with models that cannot win dropped
-    between stages) against the oracle's exhaustive loop: same winner, count and
-    mask; the dumped counts are complete for every model that reaches the best
-    count and never exceed the true count elsewhere."""
+                                         (35, 14000, 0.8), (36, 5000, 0.05), (37, 1100, 0.97), (38, 2047, 0.7)])
+def test_pruned_scoring_selects_the_same_model(gpu_ctx, oracle, model, seed, n, frac, prune_mode):
+    """Fixed-count scoring with models that cannot win dropped along the way (the
+    default schedule, 1, and the two earlier ones) against the oracle's exhaustive
+    loop: same winner, count and mask; the dumped counts are complete for every
+    model that reaches the best count and never exceed the true count elsewhere."""
     p1, p2, _, _ = synth.two_view(n, seed, inlier_frac=frac)
     nh = 256
     m = 5 if model == 0 else 7
     thr = 1.0 if model == 0 else 3.0
     K = synth.REF_K if model == 0 else None
     o = oracle.ransac(p1, p2, K, model=model, prob=0.99, threshold=thr, fixed_count=nh, want_counts=True)
-    if model == 0:
-        M, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, K, prob=0.99, threshold=thr,
-                                              mode=matcher.RANSAC_FIXED, n_hyp=nh)
-    else:
-        M, mask, r = matcher.findFundamentalMat(gpu_ctx, p1, p2, ransacReprojThreshold=thr, confidence=0.99,
-                                                mode=matcher.RANSAC_FIXED, n_hyp=nh)
+    gpu_ctx.check(gpu_ctx._L.sfm_gpu_debug_set_score_prune(gpu_ctx.handle, prune_mode))
+    try:
+        if model == 0:
+            M, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, K, prob=0.99, threshold=thr,
+                                                  mode=matcher.RANSAC_FIXED, n_hyp=nh)
+        else:
+            M, mask, r = matcher.findFundamentalMat(gpu_ctx, p1, p2, ransacReprojThreshold=thr, confidence=0.99,
+                                                    mode=matcher.RANSAC_FIXED, n_hyp=nh)
+    finally:
+        gpu_ctx._L.sfm_gpu_debug_set_score_prune(gpu_ctx.handle, 1)
     _, _, counts, _ = _dump(gpu_ctx, nh, m)
     assert r["ok"] == o["ok"] and r["n_inliers"] == o["n_inliers"]
     assert (mask == o["mask"]).all()
