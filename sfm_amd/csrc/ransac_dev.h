@@ -123,16 +123,16 @@ hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int
 hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp,
                                int gen_rows = 0);
 // staged (fixed-count mode): every model is scored on an opening stretch of the
-// points; the list is then ordered by those counts, its best few are completed
-// (the largest of their counts bounds the winner's from below), and the rest runs
-// on in pieces, a wavefront of models stopping once none of them can reach the
-// bound (their counts stay partial); what is left is compacted and finished.  All
-// sizes are chosen per problem on the device.  The selected model, its count and
-// the mask are those of staged = false.
+// points; the list is then ordered by those counts and its best few are completed
+// (the largest of their counts bounds the winner's from below); four stages
+// follow, their ends chosen per problem on the device, in which a wavefront of
+// models stops at once when none of them can reach the bound any more (their
+// counts stay partial).  The selected model, its count and the mask are those of
+// staged = false.
 // filter_mode: 1 = float32 filter with a rigorous bound in front of the double
 // precision test, 0 = double precision only (same counts).  prune_mode: 0 = never
 // drop a model, 1 = as described above, 2 / 3 = the earlier schedule (two stages sized from the
-// opening stretch's best count, two cuts / one cut).
+// opening stretch's best count, the list compacted between them, two cuts / one cut).
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
                                int n_hyp, bool staged, int filter_mode, int prune_mode);
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap);

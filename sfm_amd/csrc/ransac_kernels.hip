@@ -1768,86 +1768,16 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
     }
 }
 
-// Sequential scoring with cuts: a wavefront takes 64 consecutive models of the
-// list (ordered by ransac_sortplan_kernel so that neighbours are of like quality)
-// through the points [R_S0, R_S1) in pieces of SEQ_PIECE, and after every piece
-// drops out once none of its models can still reach the bound B = R_BOUND
-// (count so far + points left < B: such a model can neither win nor tie).  The
-// first top_groups groups of the list, which mostly live to the end, are instead
-// scored over the whole stretch in `pieces` equal parts by one wavefront each,
-// without cuts.  grid = (problems, items): the long items of every problem are
-// dispatched first.
-constexpr int SEQ_PIECE = 128;
-template <int MODEL>
-__global__ void __launch_bounds__(64) ransac_score_seq_kernel(const RansacProb* __restrict__ probs, int use_filter,
-                                                              int top_groups, int pieces)
-{
-    __shared__ unsigned short parked[SCORE_QCAP * 64];
-    const RansacProb pb = probs[blockIdx.x];
-    const int nlist = __builtin_amdgcn_readfirstlane(pb.result[R_NLIST]);
-    const int n = __builtin_amdgcn_readfirstlane(*pb.n_ptr);
-    const int s0 = __builtin_amdgcn_readfirstlane(pb.result[R_S0]);
-    const int s1 = min(n, __builtin_amdgcn_readfirstlane(pb.result[R_S1]));
-    if (s0 >= s1) return;
-    const int item = blockIdx.y;
-    const int groups = (nlist + 63) / 64;
-    const int top = min(top_groups, groups);
-    int group, i_begin = s0, i_end = s1;
-    const bool seq = item >= top_groups * pieces;
-    if (seq) {
-        group = top + (item - top_groups * pieces);
-    } else {
-        group = item / pieces;
-        if (group >= top) return;
-        const int len = (((s1 - s0) + pieces - 1) / pieces + 3) & ~3;
-        i_begin = s0 + (item % pieces) * len;
-        i_end = min(s1, i_begin + len);
-    }
-    if (group >= groups || i_begin >= i_end) return;
-    const int lane = threadIdx.x;
-    const bool active = group * 64 + lane < nlist;
-    const int e = pb.list[active ? group * 64 + lane : group * 64];
-    const float R = __int_as_float(__builtin_amdgcn_readfirstlane(pb.result[R_MAXABS]));
-    if (!seq) {
-        ScoreLane<MODEL> m;
-        m.load(pb, e, R);
-        const int cnt = score_span<MODEL>(pb, m, i_begin, i_end, parked, lane, use_filter);
-        if (active && cnt != 0) atomicAdd(&pb.counts[e], cnt);
-        return;
-    }
-    const int bound = __builtin_amdgcn_readfirstlane(pb.result[R_BOUND]);
-    const int cnt0 = pb.counts[e];  // over [0, s0): nobody else touches this model's count during this launch
-    // many wavefronts hold nothing but models the opening stretch has already ruled out
-    if (__builtin_amdgcn_ballot_w64(active && cnt0 + (n - i_begin) >= bound) == 0ull) return;
-    int cnt = cnt0;
-    for (int i0 = i_begin; i0 < i_end; i0 += SEQ_PIECE) {
-        const int i1 = min(i_end, i0 + SEQ_PIECE);
-        // The model is set up anew for every piece (a few per cent of a piece's work):
-        // kept across the loop, its coefficients and filter constants add to the registers
-        // of the double-precision tests and halve the wavefronts a SIMD can hold.
-        int ee = e;
-        asm volatile("" : "+v"(ee));
-        ScoreLane<MODEL> m;
-        m.load(pb, ee, R);
-        cnt += score_span<MODEL>(pb, m, i0, i1, parked, lane, use_filter);
-        const bool alive = active && cnt + (n - i1) >= bound;
-        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
-    }
-    if (active) pb.counts[e] = cnt;
-}
-
 // Between the opening stretch [0, R_S0), on which every listed model has been
-// counted, and the sequential stage.  One workgroup per problem:
+// counted, and the stages that follow.  One workgroup per problem:
 //  * orders the list by descending partial count (counting sort; the order
 //    inside a bucket is whatever the atomics make it: only cost depends on it),
 //  * completes the SORT_TOP best of them over all remaining points and takes
 //    them off the list: the largest of their counts is the bound B (R_BOUND),
 //    a lower bound of the winner's count,
-//  * sets the end R_S1 of the sequential stage: far enough for a model that
-//    misses nearly every point to be dropped (it is dropped once its misses
-//    exceed n - B), at least SEQ_MIN points.
+//  * sets the ends R_S1, R_MID, R_S3 of the stages that follow and the count of
+//    groups the first of them has to look at (R_LIVE).
 constexpr int SORT_TOP = 8;
-constexpr int SEQ_MIN = 1024;
 
 // Entries base + tid + 1024 k (k < 8) of a problem's list and their counts, all
 // loads of one kind issued together: these one-workgroup kernels are chains of
@@ -1898,7 +1828,7 @@ __device__ __forceinline__ int count_exact_strided(const RansacProb& pb, const d
     return add;
 }
 
-__global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb* __restrict__ probs, int sequential)
+__global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb* __restrict__ probs)
 {
     __shared__ int hist[SCORE_OPENING + 1];
     __shared__ int s_add[SORT_TOP];
@@ -1995,11 +1925,7 @@ __global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb*
             pb.result[R_NLIST] = nlist - top;
             pb.result[R_LIVE] = (nlist - top + 63) / 64;
             auto up128 = [](int v) { return (v + 127) / 128 * 128; };
-            if (sequential) {
-                int s1 = s0 + up128(max(SEQ_MIN, (int)(1.5 * (double)(n - bound))));
-                if (n - s1 < 256) s1 = n;  // not worth another stage
-                pb.result[R_S1] = s1;
-            } else {
+            {
                 // A model that misses nearly every point falls out of reach once its misses
                 // exceed n - bound: the first stage ends just past that, where most of the
                 // list stops; the later stages grow, as fewer and fewer models reach them.
@@ -2507,30 +2433,13 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     // still in play keeps most of those from looking at their models at all.
     if (staged && prune_mode == 1 && cap >= 1024) {
         score(SCORE_OPENING / 2, -1, R_S0, 2, groups, INT_MAX, false);
-        hipLaunchKernelGGL(ransac_sortplan_kernel, dim3(n_prob), dim3(1024), 0, s, probs, 0);
+        hipLaunchKernelGGL(ransac_sortplan_kernel, dim3(n_prob), dim3(1024), 0, s, probs);
         // pieces per stage: what a stage of the largest problem needs at 128 points a piece
         const int p1 = std::max(1, std::min(8, cap / 4 / 128)), p4 = std::max(1, std::min(16, cap / 512));
         score(0, R_S0, R_S1, p1, groups, INT_MAX, false, R_LIVE);
         score(0, R_S1, R_MID, std::max(2, p4 / 8), groups, INT_MAX, false, R_LIVE + 1);
         score(0, R_MID, R_S3, std::max(4, p4 / 4), groups, INT_MAX, false, R_LIVE + 2);
         score(0, R_S3, -1, p4, groups, INT_MAX, false, R_LIVE + 3);
-    } else if (staged && prune_mode == 4 && cap >= 1024) {
-        // Kept for comparison: after the ordering, one stage of sequential pieces in which a
-        // wavefront of models stops as soon as none of them can reach the bound any more
-        // (ransac_score_seq_kernel), a compaction with a renewed bound, and the rest.
-        score(SCORE_OPENING, -1, R_S0, 1, groups, INT_MAX, false);
-        hipLaunchKernelGGL(ransac_sortplan_kernel, dim3(n_prob), dim3(1024), 0, s, probs, 1);
-        const int top_groups = std::max(1, std::min(8, (int)groups / 8)), pieces = 4;
-        const dim3 grid_seq(n_prob, top_groups * pieces + (groups > (unsigned)top_groups ? groups - top_groups : 0));
-        if (model == SFM_GPU_MODEL_ESSENTIAL)
-            hipLaunchKernelGGL((ransac_score_seq_kernel<SFM_GPU_MODEL_ESSENTIAL>), grid_seq, dim3(64), 0, s, probs,
-                               filter_mode, top_groups, pieces);
-        else
-            hipLaunchKernelGGL((ransac_score_seq_kernel<SFM_GPU_MODEL_FUNDAMENTAL>), grid_seq, dim3(64), 0, s, probs,
-                               filter_mode, top_groups, pieces);
-        hipLaunchKernelGGL(ransac_prune_kernel, dim3(n_prob), dim3(1024), 0, s, probs, (int)R_S1);
-        const int depth = std::max(1, std::min(32, cap / 1024));
-        score(128, R_S1, -1, std::min(32, 2 * depth), (groups + 15) / 16, INT_MAX, true);
     } else if (staged && prune_mode >= 2 && cap >= 1024) {
         // The earlier schedule, kept for comparison: stages sized from the opening
         // stretch's best count, a cut between them (prune_mode 2: two cuts, 3: one).
