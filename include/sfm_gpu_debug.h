@@ -75,11 +75,12 @@ int sfm_gpu_debug_set_score_filter(sfm_gpu_ctx* ctx, int on);
  * the points and, between stages, drops the models that provably cannot reach
  * the best count (their entries in the dumped counts stay partial, never above
  * the true count).  0 switches the pruning off so that every dumped count is
- * complete; 1 (default) on: the list ordered by the counts of an opening
- * stretch, then stages over which whole wavefronts of models that cannot reach
- * the bound any more stop at once; 2 and 3: the earlier schedule of two stages
- * sized from that stretch, with compaction between them (two cuts or one).  The
- * selected model, its inlier count and the mask are the same
+ * complete; 1 (default) on: for a batch of eight problems or more the list is
+ * ordered by the counts of an opening stretch and stages follow over which whole
+ * wavefronts of models that cannot reach the bound any more stop at once (4: the
+ * same for any batch); smaller batches, and 2 and 3 always, take two stages
+ * sized from that stretch with the list compacted between them (two cuts, 3: one).
+ * The selected model, its inlier count and the mask are the same
  * in every mode. */
 int sfm_gpu_debug_set_score_prune(sfm_gpu_ctx* ctx, int on);
 

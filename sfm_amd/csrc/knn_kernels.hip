@@ -41,14 +41,37 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t p)
 // (v - 128), validates them and writes the per-row constants.  Rows
 // n..rows_alloc-1 are written as padding.  Every load instruction reads whole
 // 128-B pieces of 8 rows and every store writes whole 128-B rows.
-__device__ __forceinline__ uint32_t pack4_checked(float a, float b, float c, float d, bool& bad)
+// Four float32 values that should be integers 0..255 -> their bytes, minus 128.
+// v + 2^23 has the bit pattern 0x4B0000vv exactly when v is such an integer (or
+// was rounded to one): the low byte is the value, the upper 24 bits are checked
+// through the running OR / AND of all patterns, and (v + 2^23) - 2^23 - v, which
+// is +0 only when nothing was rounded away, through the running OR of its bits
+// (a NaN or an infinity fails the first check, -0 passes as 0).  Two packed
+// additions per pair of values instead of a conversion each way and three
+// compares per value: the conversion kernel runs beside other work and its
+// vector instructions are what it takes from it.
+typedef float pf2 __attribute__((ext_vector_type(2)));
+struct ValueCheck {
+    uint32_t any = 0u, all = 0xFFFFFFFFu, resid = 0u;
+    __device__ __forceinline__ bool bad() const
+    {
+        return (any & 0xFFFFFF00u) != 0x4B000000u || (all & 0xFFFFFF00u) != 0x4B000000u || resid != 0u;
+    }
+};
+__device__ __forceinline__ uint32_t pack4_checked(float4 f, ValueCheck& chk)
 {
-    const int ia = (int)a, ib = (int)b, ic = (int)c, id = (int)d;
-    bad |= !(a >= 0.f && a <= 255.f && b >= 0.f && b <= 255.f && c >= 0.f && c <= 255.f && d >= 0.f &&
-             d <= 255.f) ||
-           (float)ia != a || (float)ib != b || (float)ic != c || (float)id != d;
-    return ((uint32_t)(ia & 255) | ((uint32_t)(ib & 255) << 8) | ((uint32_t)(ic & 255) << 16) |
-            ((uint32_t)(id & 255) << 24)) ^ 0x80808080u;
+    const pf2 magic = {8388608.f, 8388608.f};
+    const pf2 a = {f.x, f.y}, b = {f.z, f.w};
+    const pf2 ta = a + magic, tb = b + magic;
+    const pf2 da = (ta - magic) - a, db = (tb - magic) - b;
+    const uint32_t t0 = __float_as_uint(ta.x), t1 = __float_as_uint(ta.y), t2 = __float_as_uint(tb.x),
+                   t3 = __float_as_uint(tb.y);
+    chk.any |= (t0 | t1) | (t2 | t3);
+    chk.all &= (t0 & t1) & (t2 & t3);
+    chk.resid |= (__float_as_uint(da.x) | __float_as_uint(da.y)) | (__float_as_uint(db.x) | __float_as_uint(db.y));
+    const uint32_t lo = __builtin_amdgcn_perm(t1, t0, 0x0c0c0400u);  // (t0.b0, t1.b0, 0, 0)
+    const uint32_t hi = __builtin_amdgcn_perm(t3, t2, 0x04000c0cu);  // (0, 0, t2.b0, t3.b0)
+    return (lo | hi) ^ 0x80808080u;
 }
 
 template <int DTYPE>
@@ -68,6 +91,7 @@ __global__ void __launch_bounds__(256) prep_rows_kernel(const PrepJob* __restric
     const bool wide = (((uintptr_t)src | step) & 15) == 0;  // 16-B loads allowed
     uint32_t P[4] = {0u, 0u, 0u, 0u};  // value 128 -> byte 0
     bool bad = false;
+    ValueCheck chk;
     if (row < n) {
         const unsigned char* rp = src + (size_t)row * step;
         if (DTYPE == SFM_GPU_DESC_F32) {
@@ -78,8 +102,9 @@ __global__ void __launch_bounds__(256) prep_rows_kernel(const PrepJob* __restric
                 float4 f;
                 if (wide) f = *(const float4*)fp;
                 else f = make_float4(fp[0], fp[1], fp[2], fp[3]);
-                P[j] = pack4_checked(f.x, f.y, f.z, f.w, bad);
+                P[j] = pack4_checked(f, chk);
             }
+            bad = chk.bad();
         } else {
             // the lane's 16 consecutive bytes
             const unsigned char* bp = rp + seg * 16;

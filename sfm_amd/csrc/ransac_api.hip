@@ -258,7 +258,7 @@ int sfm_gpu_debug_set_score_filter(sfm_gpu_ctx* ctx, int on)
 int sfm_gpu_debug_set_score_prune(sfm_gpu_ctx* ctx, int on)
 {
     if (!ctx) return SFM_GPU_ERR_ARG;
-    if (on < 0 || on > 3) return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "score prune mode %d", on);
+    if (on < 0 || on > 4) return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "score prune mode %d", on);
     ctx->score_prune = on;
     return SFM_GPU_OK;
 }

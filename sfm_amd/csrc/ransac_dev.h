@@ -131,8 +131,9 @@ hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_pro
 // staged = false.
 // filter_mode: 1 = float32 filter with a rigorous bound in front of the double
 // precision test, 0 = double precision only (same counts).  prune_mode: 0 = never
-// drop a model, 1 = as described above, 2 / 3 = the earlier schedule (two stages sized from the
-// opening stretch's best count, the list compacted between them, two cuts / one cut).
+// drop a model, 1 = as described above for batches of eight problems or more (4: for any batch),
+// 2 / 3 (and 1 for smaller batches) = two stages sized from the opening stretch's best count, the
+// list compacted between them, two cuts / one cut.
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
                                int n_hyp, bool staged, int filter_mode, int prune_mode);
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap);

@@ -2431,6 +2431,11 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     // list the models that have fallen out of reach sit together, so whole
     // wavefronts of them stop at the door, and a count of the leading groups
     // still in play keeps most of those from looking at their models at all.
+    // (a batch of few problems has too few wavefronts in the later stages to hide
+    // their start-up, and one workgroup ordering a long list is slow: such a batch,
+    // e.g. one 32768-row pair with 4096 five-point hypotheses, takes the schedule below)
+    if (staged && prune_mode == 1 && n_prob < 8) prune_mode = 2;
+    if (prune_mode == 4) prune_mode = 1;  // tests: the ordered stages whatever the batch
     if (staged && prune_mode == 1 && cap >= 1024) {
         score(SCORE_OPENING / 2, -1, R_S0, 2, groups, INT_MAX, false);
         hipLaunchKernelGGL(ransac_sortplan_kernel, dim3(n_prob), dim3(1024), 0, s, probs);
@@ -2441,8 +2446,8 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
         score(0, R_MID, R_S3, std::max(4, p4 / 4), groups, INT_MAX, false, R_LIVE + 2);
         score(0, R_S3, -1, p4, groups, INT_MAX, false, R_LIVE + 3);
     } else if (staged && prune_mode >= 2 && cap >= 1024) {
-        // The earlier schedule, kept for comparison: stages sized from the opening
-        // stretch's best count, a cut between them (prune_mode 2: two cuts, 3: one).
+        // Stages sized from the opening stretch's best count, the list compacted at a
+        // cut between them (prune_mode 2: two cuts, 3: one).
         score(SCORE_OPENING, -1, R_S0, 1, groups, INT_MAX, false);
         // the first stage may take up to a quarter of the capacity: with the ratio
         // test leaving well under half of the queries, that covers outlier shares

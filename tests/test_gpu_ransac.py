@@ -213,7 +213,7 @@ def test_scoring_filter_is_exact_on_near_threshold_points(gpu_ctx, oracle, full_
     assert 1500 + 200 < best < 6000 - 200
 
 
-@pytest.mark.parametrize("prune_mode", [1, 2, 3])
+@pytest.mark.parametrize("prune_mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("model", [0, 1])
 @pytest.mark.parametrize("seed,n,frac", [(31, 400, 0.9), (32, 513, 0.5), (33, 3300, 0.93), (34, 3300, 0.35),
                                          (35, 14000, 0.8), (36, 5000, 0.05), (37, 1100, 0.97), (38, 2047, 0.7)])
