@@ -921,13 +921,120 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
         for (int w = 0; w < wv; ++w) base += s_wcount[w];
         if (need) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = qi;
     }
+    __shared__ int s_list2[RESCAN_QPW];
+    __shared__ int s_n2;
+    if (threadIdx.x == 0) s_n2 = 0;
     __syncthreads();
     const int s_count = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
-    const int n_need = s_count;
+    int n_need = s_count;
+    const int* list = s_list;
+    // Step 2a, pair pipeline only (what is kept of a query is its best match and
+    // the ratio verdict): sixteen lanes per query compute the exact distances of
+    // the BEST group's 16 rows only.  With dA1 <= dA2 the two smallest of those and
+    // L = qn + 2 x2 - 2 KEY (x2 = minimum of the second group): every row outside
+    // the best group has d2 >= L, and the second group's minimum row has d2 = L or
+    // L + 1.  So when dA1 < L the best match is the best of the group, and the
+    // second distance is min(dA2, L) or min(dA2, L + 1): the verdict of
+    // main.cpp:192 is evaluated on both, exactly as the reference does (float
+    // square roots, compare in double), and when they agree the query is done
+    // with half the rows gathered.  Anything else (no second group, a tie between
+    // the groups, distances at 2^22 where float square roots collide, a verdict
+    // that hangs on that one unit) goes through step 2b below.
+    if (skip_r2 > 0.0) {
+        const int l16 = threadIdx.x & 15;
+        const int sg = l16 & 7, rq = l16 >> 3;
+        for (int it = threadIdx.x >> 4; it < n_need; it += 16) {
+            const int qi = s_list[it];
+            const int q = wg.qblock * RESCAN_QPW + qi;
+            const u64 c1 = s_c[qi][0], c2 = s_c[qi][1];
+            const bool have_b = c2 != NONE;
+            const uint32_t ida = (uint32_t)c1;
+            const int base_a = (int)(ida >> SB) * UROWS + 4 * (int)(ida & ((1u << SB) - 1u));
+            const v4i qv = *(const v4i*)(job.q_desc + (size_t)q * DIM + sg * 16);
+            // candidate c = 2 * it2 + rq of the group is row base_a + JSTRIDE * (c >> 2) + (c & 3)
+            v4i tv[8];
+#pragma unroll
+            for (int it2 = 0; it2 < 8; ++it2) {
+                const int r = base_a + JSTRIDE * (it2 >> 1) + 2 * (it2 & 1) + rq;
+                tv[it2] = *(const v4i*)(job.t_desc + (size_t)r * DIM + sg * 16);
+            }
+            int part[8];
+#pragma unroll
+            for (int it2 = 0; it2 < 8; ++it2) {
+                int acc = __builtin_amdgcn_sdot4(qv[0], tv[it2][0], 0, false);
+                acc = __builtin_amdgcn_sdot4(qv[1], tv[it2][1], acc, false);
+                acc = __builtin_amdgcn_sdot4(qv[2], tv[it2][2], acc, false);
+                acc = __builtin_amdgcn_sdot4(qv[3], tv[it2][3], acc, false);
+                part[it2] = acc;
+            }
+            // reduce over the 8 segments while scattering the 8 candidates of this half:
+            // afterwards the lane holds the whole dot product of candidate 2 * sg + rq
+            int r4[4], r2[2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool up = (sg & 4) != 0;
+                const int mine = up ? part[j + 4] : part[j];
+                const int send = up ? part[j] : part[j + 4];
+                r4[j] = mine + __shfl_xor(send, 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool up = (sg & 2) != 0;
+                const int mine = up ? r4[j + 2] : r4[j];
+                const int send = up ? r4[j] : r4[j + 2];
+                r2[j] = mine + __shfl_xor(send, 2);
+            }
+            const int qt = ((sg & 1) ? r2[1] : r2[0]) + __shfl_xor((sg & 1) ? r2[0] : r2[1], 1);
+            const int cand = 2 * sg + rq;
+            const int row = base_a + JSTRIDE * (sg >> 1) + 2 * (sg & 1) + rq;
+            const bool row_ok = row < job.n_train;
+            const int qn = job.q_qn[q];
+            const int tn = job.t_qn[row_ok ? row : 0];
+            uint32_t e = 0xFFFFFFFFu;  // (d2 << 5) | candidate: ascending (d2, row)
+            if (row_ok) e = ((uint32_t)(qn + tn - 2 * qt) << 5) | (uint32_t)cand;
+            uint32_t e1 = e, e2 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const uint32_t b1 = (uint32_t)__shfl_xor((int)e1, off), b2 = (uint32_t)__shfl_xor((int)e2, off);
+                const uint32_t lo = umin32(e1, b1);
+                e2 = umin32(umax32(e1, b1), umin32(e2, b2));
+                e1 = lo;
+            }
+            const int p1 = (int)(e1 & 31u);
+            const int row1 = __shfl(row, ((p1 & 1) << 3) | (p1 >> 1), 16);
+            if (l16 == 0) {
+                bool done = false;
+                if (have_b && e1 != 0xFFFFFFFFu) {
+                    const int32_t dA1 = (int32_t)(e1 >> 5);
+                    const int32_t dA2 = e2 != 0xFFFFFFFFu ? (int32_t)(e2 >> 5) : 0x7FFFFFFF;
+                    const int32_t L = qn - 2 * KEY_OFFSET + 2 * (int32_t)(uint32_t)(c2 >> 32);
+                    if (dA1 < L && L + 1 < (1 << 22)) {
+                        const float f1 = sqrt_d2((uint32_t)dA1);
+                        const float f_lo = sqrt_d2((uint32_t)min(dA2, L)), f_hi = sqrt_d2((uint32_t)min(dA2, L + 1));
+                        const bool v_lo = (double)f1 < ratio * (double)f_lo, v_hi = (double)f1 < ratio * (double)f_hi;
+                        if (v_lo == v_hi) {
+                            done = true;
+                            sfm_gpu_dmatch m;
+                            m.queryIdx = q;
+                            m.trainIdx = row1;
+                            m.imgIdx = 0;
+                            m.distance = f1;
+                            job.out[(size_t)q * k] = m;
+                            job.counts[q] = v_lo ? 2 : 0;
+                        }
+                    }
+                }
+                if (!done) s_list2[atomicAdd(&s_n2, 1)] = qi;
+            }
+        }
+        __syncthreads();
+        n_need = s_n2;
+        list = s_list2;
+    }
     const int l = threadIdx.x & 31;
-    // Step 2: the eight 32-lane groups take the listed queries in turn.
+    // Step 2b: the eight 32-lane groups take the listed queries in turn.
     for (int it = threadIdx.x >> 5; it < n_need; it += 8) {
-    const int qi = s_list[it];
+    const int qi = list[it];
     const int q = wg.qblock * RESCAN_QPW + qi;
     const u64 c1 = s_c[qi][0], c2 = s_c[qi][1], c3 = s_c[qi][2];
     const uint32_t third_x = (uint32_t)(c3 >> 32);  // 0xFFFFFFFF when there is no third group

@@ -342,12 +342,16 @@ def trial_pnp(ctx, rng, idx, stats):
     return 0
 
 
-def run(seconds, seed, only="", ctx=None, quiet=False):
-    """Draws trials for `seconds`; returns (fails, trials, stats)."""
+def run(seconds, seed, only="", ctx=None, quiet=False, score_prune=None):
+    """Draws trials for `seconds`; returns (fails, trials, stats).
+    score_prune: scoring schedule of the fixed-count mode to force on the context
+    (sfm_gpu_debug_set_score_prune; 4 = the ordered stages for any batch size)."""
     rng = np.random.default_rng(seed)
     own = ctx is None
     if own:
         ctx = matcher.Context(0)
+    if score_prune is not None:
+        ctx.check(ctx._L.sfm_gpu_debug_set_score_prune(ctx.handle, int(score_prune)))
     bf = matcher.BFMatcher(ctx)
     stats = dict(ransac=0, ransac_ok=0, model_last_bits=0, pose=0, knn=0, pairs=0, tracks=0, sequence=0, pnp=0)
     only = [s for s in only.split(",") if s]
@@ -378,6 +382,8 @@ def run(seconds, seed, only="", ctx=None, quiet=False):
         if not quiet and time.time() - last > 20:
             last = time.time()
             print("[%4.0fs] trials=%d fails=%d %s" % (last - t0, idx, fails, stats), flush=True)
+    if score_prune is not None:
+        ctx.check(ctx._L.sfm_gpu_debug_set_score_prune(ctx.handle, 1))
     if own:
         ctx.close()
     return fails, idx, stats
@@ -388,8 +394,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", default="", help="comma list of ransac,knn,pairs,tracks,sequence,pnp")
+    ap.add_argument("--score-prune", type=int, default=None,
+                    help="force a scoring schedule of the fixed-count mode (4: ordered stages for any batch)")
     args = ap.parse_args()
-    fails, idx, stats = run(args.seconds, args.seed, args.only)
+    fails, idx, stats = run(args.seconds, args.seed, args.only, score_prune=args.score_prune)
     print("done: trials=%d fails=%d %s" % (idx, fails, stats), flush=True)
     sys.exit(1 if fails else 0)
 

@@ -245,6 +245,49 @@ def test_pipeline_on_tie_heavy_descriptors(gpu_ctx, oracle, ratio):
         im.close()
 
 
+def test_verdicts_that_hang_on_one_unit_of_squared_distance(gpu_ctx, oracle):
+    """The pipeline's neighbour extraction computes exact distances for the best
+    group of 16 train rows only and knows the second distance up to one unit
+    (d2 = L or L + 1) unless it looks closer.  Here every query's two nearest rows
+    sit in different groups at d1^2 = 100 and d2^2 = 400 or 401, and the ratio 0.5
+    passes exactly the latter: 10 < 0.5 * sqrt(401) but not 10 < 0.5 * 20."""
+    n_q, n_t = 700, 2400
+    rng = np.random.default_rng(77)
+    Q = synth.sift_like(n_q, 501)
+    T = synth.sift_like(n_t, 502)
+    want_pass = rng.integers(0, 2, n_q).astype(bool)
+    for i in range(n_q):
+        small = np.argsort(Q[i])[:3]                   # three coordinates with room to grow
+        near, far = Q[i].copy(), Q[i].copy()
+        near[small[0]] += 10.0                          # d^2 = 100
+        far[small[1]] += 20.0                           # d^2 = 400
+        if want_pass[i]:
+            far[small[2]] += 1.0                        # d^2 = 401
+        T[i] = near
+        T[n_q + 16 + ((i * 37) % (n_t - n_q - 16))] = far   # another group of 16 rows, scattered
+    # (a later query's far row may overwrite an earlier one's: the oracle sees the same images)
+    kq = np.stack([rng.uniform(0, synth.IMG_W, n_q), rng.uniform(0, synth.IMG_H, n_q)], 1).astype(np.float32)
+    kt = np.stack([rng.uniform(0, synth.IMG_W, n_t), rng.uniform(0, synth.IMG_H, n_t)], 1).astype(np.float32)
+    imgs = [matcher.Image(gpu_ctx, Q, kq), matcher.Image(gpu_ctx, T, kt)]
+    pairs = np.array([[0, 1]] * 8, np.int32)
+    n_good, n_inl, sel = matcher.match_pairs(gpu_ctx, imgs, pairs, None, ratio=0.5, model=matcher.MODEL_FUNDAMENTAL,
+                                             mode=matcher.RANSAC_FIXED, n_hyp=32, prob=0.99, threshold=1e6,
+                                             want_matches=True)
+    m, c = oracle.knn_match(Q, T, 2, nthreads=4)
+    good = m[oracle.ratio_test(m, c, 0.5), 0]
+    d2 = np.rint(m["distance"].astype(np.float64) ** 2)
+    assert ((d2[:, 0] == 100) & ((d2[:, 1] == 400) | (d2[:, 1] == 401))).sum() > 500   # the construction held
+    assert 100 < len(good) < n_q - 100
+    for p in range(len(pairs)):
+        assert n_good[p] == len(good)
+        if n_inl[p] == len(good):
+            assert (sel[p]["queryIdx"] == good["queryIdx"]).all() and (sel[p]["trainIdx"] == good["trainIdx"]).all()
+            assert (sel[p]["distance"].view(np.uint32) == good["distance"].view(np.uint32)).all()
+    assert (n_inl == len(good)).any()
+    for im in imgs:
+        im.close()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.uint8])
 def test_images_prepared_in_device_memory_match_owned_images(gpu_ctx, dtype):
     """Descriptors that already sit in device memory (float rows as
