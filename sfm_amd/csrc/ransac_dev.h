@@ -29,6 +29,7 @@ enum {
     R_S3 = 16,     // a third cut between R_MID and n
     R_LIVE = 17,   // R_LIVE + k, k = 0..4: leading groups of 64 of the ordered list in which some model could
                    // still reach the bound when stage k of the scoring began (an upper bound; stage k writes k + 1)
+    R_TOP = 22,    // models at the head of the ordered list (list2) that were completed up front: the stages start behind them
     R_COUNT = 24,
     // adaptive mode (the staged scoring of the fixed-count mode does not run there):
     R_NITERS = R_S1,  // the loop bound as it stands, shrinking with every better model

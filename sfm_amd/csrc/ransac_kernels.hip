@@ -1719,11 +1719,12 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
                                                           int use_filter, int slot_begin, int slot_end,
                                                           int list_limit, int live_slot)
 {
-    // live_slot >= 0: grid = (problems, pieces, groups), so that the groups at the head of the
+    // live_slot >= 0 or -2: grid = (problems, pieces, groups), so that the groups at the head of the
     // ordered list, the only ones with work in the later stages, are dispatched first and spread
     // over the whole chip (consecutive workgroups are placed on the same compute unit until it
-    // is full: live groups side by side in the grid would share a few units while the rest idle)
-    const bool by_group = !STRIDED && live_slot >= 0;
+    // is full: live groups side by side in the grid would share a few units while the rest idle).
+    // The opening stretch (-2: this order, no cuts) gains from it as well.
+    const bool by_group = !STRIDED && (live_slot >= 0 || live_slot == -2);  // -2: that grid order, no cuts
     const unsigned bx = by_group ? blockIdx.z : blockIdx.x, by = blockIdx.y, bz = by_group ? blockIdx.x : blockIdx.z;
     const unsigned gdx = by_group ? gridDim.z : gridDim.x;
     const RansacProb pb = probs[bz];
@@ -1748,7 +1749,9 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
     const float R = __int_as_float(__builtin_amdgcn_readfirstlane(pb.result[R_MAXABS]));
     for (int g0 = (bx * SCORE_WAVES + wv) * 64; g0 < nlist; g0 += gdx * SCORE_WAVES * 64) {
         const bool active = g0 + lane < nlist;
-        const int e = pb.list[active ? g0 + lane : g0];
+        // the stages read the ordered list where ransac_sortplan_kernel left it
+        const int32_t* lst = (!STRIDED && live_slot >= 0) ? pb.list2 + __builtin_amdgcn_readfirstlane(pb.result[R_TOP]) : pb.list;
+        const int e = lst[active ? g0 + lane : g0];
         if (!STRIDED && live_slot >= 0) {
             // (every piece of the group sees the same counts: the stage before is complete)
             const int bound = __builtin_amdgcn_readfirstlane(pb.result[R_BOUND]);
@@ -1796,32 +1799,32 @@ __device__ __forceinline__ void load_entries8(const RansacProb& pb, int base, in
 }
 
 // Inliers of model M among the points first, first + stride, ... < n, by the
-// procedure of the mask, four points' loads in flight at a time.
+// procedure of the mask, eight points' loads in flight at a time.
 __device__ __forceinline__ int count_exact_strided(const RansacProb& pb, const double* M, int first, int stride, int n)
 {
     int add = 0;
-    for (int i = first; i < n; i += 4 * stride) {
+    for (int i = first; i < n; i += 8 * stride) {
         if (pb.model == SFM_GPU_MODEL_ESSENTIAL) {
-            double2 a[4], b[4];
+            double2 a[8], b[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 const int ii = min(i + k * stride, n - 1);
                 a[k] = *(const double2*)(pb.x1 + 2 * ii);
                 b[k] = *(const double2*)(pb.x2 + 2 * ii);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 8; ++k)
                 if (i + k * stride < n) add += sampson_inlier(M, a[k].x, a[k].y, b[k].x, b[k].y, pb.tf, pb.tlo, pb.thi);
         } else {
-            float2 a[4], b[4];
+            float2 a[8], b[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 const int ii = min(i + k * stride, n - 1);
                 a[k] = *(const float2*)(pb.f1 + 2 * ii);
                 b[k] = *(const float2*)(pb.f2 + 2 * ii);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 8; ++k)
                 if (i + k * stride < n) add += symepi_inlier(M, a[k].x, a[k].y, b[k].x, b[k].y, pb.tf, pb.tlo, pb.thi);
         }
     }
@@ -1831,7 +1834,7 @@ __device__ __forceinline__ int count_exact_strided(const RansacProb& pb, const d
 __global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb* __restrict__ probs)
 {
     __shared__ int hist[SCORE_OPENING + 1];
-    __shared__ int s_add[SORT_TOP];
+    __shared__ int s_add[SORT_TOP], s_top_e[SORT_TOP], s_top_c[SORT_TOP];
     const RansacProb pb = probs[blockIdx.x];
     const int tid = threadIdx.x;
     const int n = *pb.n_ptr;
@@ -1844,6 +1847,7 @@ __global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb*
         pb.result[R_MID] = n;
         pb.result[R_S3] = n;
         for (int k = 0; k < 5; ++k) pb.result[R_LIVE + k] = 0;
+        pb.result[R_TOP] = 0;
     }
     if (nlist <= 0 || s0 >= n) return;
     for (int b = tid; b <= SCORE_OPENING; b += 1024) hist[b] = 0;
@@ -1881,15 +1885,25 @@ __global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb*
         }
     }
     __syncthreads();
+    // (whoever places an entry among the first SORT_TOP also leaves it in LDS: the
+    // completion below then needs no trip to memory to learn which models it is about)
+    auto place = [&](int ent, int cnt) {
+        const int slot = atomicAdd(&hist[cnt], 1);
+        pb.list2[slot] = ent;
+        if (slot < SORT_TOP) {
+            s_top_e[slot] = ent;
+            s_top_c[slot] = cnt;
+        }
+    };
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-        if (e[k] >= 0) pb.list2[atomicAdd(&hist[c[k]], 1)] = e[k];
+        if (e[k] >= 0) place(e[k], c[k]);
     for (int base = 8192; base < nlist; base += 8192) {
         int eb[8], cb[8];
         load_entries8(pb, base, nlist, tid, eb, cb);
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (eb[k] >= 0) pb.list2[atomicAdd(&hist[min(max(cb[k], 0), SCORE_OPENING)], 1)] = eb[k];
+            if (eb[k] >= 0) place(eb[k], min(max(cb[k], 0), SCORE_OPENING));
     }
     __syncthreads();
     // the best SORT_TOP, 128 threads each, over the points the opening has not seen
@@ -1898,7 +1912,7 @@ __global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb*
         const int t = tid >> 7, j = tid & 127;
         int add = 0;
         if (t < top) {
-            const int et = pb.list2[t];
+            const int et = s_top_e[t];
             const double* Mg = pb.models + (size_t)(et / MAX_MODELS) * 90 + (et % MAX_MODELS) * 9;
             double M[9];
 #pragma unroll
@@ -1913,9 +1927,8 @@ __global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb*
     if (tid < 64) {
         int full = 0;
         if (tid < top) {
-            const int et = pb.list2[tid];
-            full = pb.counts[et] + s_add[tid];
-            pb.counts[et] = full;
+            full = s_top_c[tid] + s_add[tid];  // (the opening count of a listed model is its bucket: never clamped)
+            pb.counts[s_top_e[tid]] = full;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) full = max(full, __shfl_xor(full, off));
@@ -1923,6 +1936,7 @@ __global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb*
             const int bound = max(bound0, full);
             pb.result[R_BOUND] = bound;
             pb.result[R_NLIST] = nlist - top;
+            pb.result[R_TOP] = top;
             pb.result[R_LIVE] = (nlist - top + 63) / 64;
             auto up128 = [](int v) { return (v + 127) / 128 * 128; };
             {
@@ -1936,20 +1950,6 @@ __global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb*
                 pb.result[R_MID] = n - b2 < 256 ? n : b2;
                 pb.result[R_S3] = n - b3 < 256 ? n : b3;
             }
-        }
-    }
-    // the rest of the ordered list becomes the list
-    for (int base = 0; base < nlist - top; base += 8192) {
-        int v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int p = base + tid + 1024 * k;
-            v[k] = p < nlist - top ? pb.list2[top + p] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int p = base + tid + 1024 * k;
-            if (p < nlist - top) pb.list[p] = v[k];
         }
     }
 }
@@ -2404,7 +2404,7 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     auto score = [&](int chunk_pts, int slot_begin, int slot_end, int chunks, unsigned gx, int list_limit,
                      bool strided, int live_slot = -1) {
         const unsigned gw = (gx + SCORE_WAVES - 1) / SCORE_WAVES;
-        const dim3 grid = live_slot >= 0 ? dim3(n_prob, chunks, gw) : dim3(gw, chunks, n_prob);
+        const dim3 grid = (live_slot >= 0 || live_slot == -2) ? dim3(n_prob, chunks, gw) : dim3(gw, chunks, n_prob);
         const dim3 block(SCORE_WAVES * 64);
         const int f = filter_mode;
         if (model == SFM_GPU_MODEL_ESSENTIAL) {
@@ -2437,7 +2437,7 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     if (staged && prune_mode == 1 && n_prob < 8) prune_mode = 2;
     if (prune_mode == 4) prune_mode = 1;  // tests: the ordered stages whatever the batch
     if (staged && prune_mode == 1 && cap >= 1024) {
-        score(SCORE_OPENING / 2, -1, R_S0, 2, groups, INT_MAX, false);
+        score(SCORE_OPENING / 2, -1, R_S0, 2, groups, INT_MAX, false, -2);  // (group-major: 75 against 68 us)
         hipLaunchKernelGGL(ransac_sortplan_kernel, dim3(n_prob), dim3(1024), 0, s, probs);
         // pieces per stage: what a stage of the largest problem needs at 128 points a piece
         const int p1 = std::max(1, std::min(8, cap / 4 / 128)), p4 = std::max(1, std::min(16, cap / 512));
