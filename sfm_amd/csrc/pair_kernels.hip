@@ -54,7 +54,14 @@ __global__ void __launch_bounds__(1024) ratio_compact_kernel(const PairDev* __re
     if (tile >= n_tiles && !(tile == 0 && n_tiles == 0)) return;
     const int tid = threadIdx.x;
     int before = 0;
-    for (int j = 0; j < tile; ++j) before += ratio_keep(pd, j * 1024 + tid, ratio) ? 1 : 0;
+    // (eight tiles' loads at a time: a loop of load -> test pays a round trip per tile)
+    for (int j0 = 0; j0 < tile; j0 += 8) {
+        bool keep[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) keep[k] = j0 + k < tile && ratio_keep(pd, (j0 + k) * 1024 + tid, ratio);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) before += keep[k] ? 1 : 0;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
     if ((tid & 63) == 0) wsum[tid >> 6] = before;

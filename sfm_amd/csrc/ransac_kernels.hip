@@ -1354,10 +1354,28 @@ __global__ void __launch_bounds__(1024) ransac_compact_kernel(const RansacProb* 
     // floats order like their bit patterns); the filter's error bounds use it
     {
         int mx = 0;
-        for (int i = tid; i < n; i += 1024)
+        // one 64-byte block (four points, four planes) per thread and turn, four turns' loads in flight
+        const float4* blocks = (const float4*)pb.soa;
+        const int nblk = (n + 3) / 4;
+        for (int b0 = tid; b0 < nblk; b0 += 4 * 1024) {
+            float4 v[4][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                mx = max(mx, __float_as_int(fabsf(pb.soa[(size_t)(i >> 2) * 16 + c * 4 + (i & 3)])));
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    v[k][c] = b0 + 1024 * k < nblk ? blocks[(size_t)(b0 + 1024 * k) * 4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int valid_pts = n - 4 * (b0 + 1024 * k);  // points of the block that exist (the rest is stale)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (valid_pts > 0) mx = max(mx, __float_as_int(fabsf(v[k][c].x)));
+                    if (valid_pts > 1) mx = max(mx, __float_as_int(fabsf(v[k][c].y)));
+                    if (valid_pts > 2) mx = max(mx, __float_as_int(fabsf(v[k][c].z)));
+                    if (valid_pts > 3) mx = max(mx, __float_as_int(fabsf(v[k][c].w)));
+                }
+            }
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
         if (lane == 0) wsum[wv] = mx;
@@ -2148,11 +2166,21 @@ __global__ void __launch_bounds__(1024) ransac_select_kernel(const RansacProb* _
     }
     const int valid = min(n_hyp, pb.result[R_VALID]);
     unsigned long long best = 0;
-    for (int e = tid; e < valid * 10; e += 1024) {
-        const int c = pb.counts[e];
-        if (c >= pb.m) {
-            const unsigned long long key = ((unsigned long long)(unsigned)c << 32) | (0xFFFFFFFFu - (unsigned)e);
-            best = key > best ? key : best;
+    // (ten loads in flight per thread: as a plain loop this scan was a round trip per turn)
+    for (int e0 = tid; e0 < valid * 10; e0 += 10 * 1024) {
+        int c[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const int e = e0 + 1024 * k;
+            c[k] = e < valid * 10 ? pb.counts[e] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            if (c[k] >= pb.m) {
+                const unsigned long long key =
+                    ((unsigned long long)(unsigned)c[k] << 32) | (0xFFFFFFFFu - (unsigned)(e0 + 1024 * k));
+                best = key > best ? key : best;
+            }
         }
     }
 #pragma unroll
