@@ -84,6 +84,14 @@ int sfm_gpu_debug_set_score_filter(sfm_gpu_ctx* ctx, int on);
  * in every mode. */
 int sfm_gpu_debug_set_score_prune(sfm_gpu_ctx* ctx, int on);
 
+/* Environment, read once per process: SFM_GPU_ROCTX=1 brackets every stage of a
+ * call (the names sfm_gpu_profile_query knows: "knn2_mfma", "knn_finalize",
+ * "ratio_compact", "ransac_solve", "ransac_score", ...) in a rocTX range
+ * (roctxRangePush / Pop from librocprofiler-sdk-roctx.so or libroctx64.so, loaded
+ * on demand), so that `rocprofv3 --marker-trace --kernel-trace` shows which launches
+ * belong to which stage.  Without the variable, or without the library, nothing is
+ * loaded and nothing is called. */
+
 /* Vote counts of the four pose candidates in the last sfm_gpu_recover_pose call
  * on this context, in the order (R1,t) (R2,t) (R1,-t) (R2,-t). */
 int sfm_gpu_debug_pose_votes(sfm_gpu_ctx* ctx, int32_t* votes4);

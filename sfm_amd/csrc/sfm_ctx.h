@@ -241,13 +241,27 @@ struct sfm_gpu_ctx {
 
 namespace sfm {
 
+// rocTX ranges around the stages of a call, for `rocprofv3 --marker-trace`: on when
+// the environment has SFM_GPU_ROCTX=1 and a rocTX library can be loaded
+// (librocprofiler-sdk-roctx.so, else libroctx64.so); otherwise two null pointers.
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+const RoctxApi& roctx_api();  // sfm_gpu_api.hip
+
 // RAII bracket around one kernel launch for the per-kernel timers.
 struct ProfScope {
     sfm_gpu_ctx* c;
     KernelTimer* t = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
+    bool marked = false;
     ProfScope(sfm_gpu_ctx* ctx, const char* name) : c(ctx)
     {
+        if (roctx_api().push) {
+            roctx_api().push(name);
+            marked = true;
+        }
         if (!c || !c->profiling) return;
         if (!c->profile_only.empty() && c->profile_only != name) return;
         t = &c->timers[name];
@@ -257,6 +271,7 @@ struct ProfScope {
     }
     ~ProfScope()
     {
+        if (marked) roctx_api().pop();
         if (!t) return;
         (void)hipEventRecord(b, c->stream);
         t->pending.emplace_back(a, b);

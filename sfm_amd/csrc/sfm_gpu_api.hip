@@ -1,6 +1,7 @@
 // C ABI of libsfm_gpu: context, image preparation, k-NN matching entry points.
 #include <algorithm>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <vector>
 
@@ -223,6 +224,28 @@ hipError_t resolve_scratch(int device, void** out)
 }
 
 }  // namespace
+
+namespace sfm {
+const RoctxApi& roctx_api()
+{
+    static const RoctxApi api = [] {
+        RoctxApi a;
+        const char* on = getenv("SFM_GPU_ROCTX");
+        if (!on || on[0] != '1') return a;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                a.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+                a.pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (a.push && a.pop) return a;
+                a.push = nullptr;
+                a.pop = nullptr;
+            }
+        }
+        return a;
+    }();
+    return api;
+}
+}  // namespace sfm
 
 extern "C" {
 
