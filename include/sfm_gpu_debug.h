@@ -42,6 +42,12 @@ int sfm_gpu_debug_sweep_stamps(sfm_gpu_ctx* ctx, uint64_t* out, int n_wg);
  * sent through the exhaustive float-ranked pass. */
 int sfm_gpu_debug_redo_count(sfm_gpu_ctx* ctx, int32_t* out);
 
+/* Timing build only (SFM_GPU_ERR_UNSUPPORTED otherwise): per-wavefront stamps of
+ * the scoring launches since the last call, four 64-bit words each -- realtime
+ * counter (100 MHz) at entry and at exit, hardware id | XCC id << 32, the
+ * launch's stage tag -- at most n_max of them; *count = how many were copied. */
+int sfm_gpu_debug_score_stamps(sfm_gpu_ctx* ctx, uint64_t* out, int n_max, int32_t* count);
+
 /* c[32][32] (int32) = a[32][32] * b^T with b given as [32 columns][32 k], all
  * host pointers, through one v_mfma_i32_32x32x32_i8 loaded the way the
  * distance kernel loads its operands. */

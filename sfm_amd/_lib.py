@@ -117,6 +117,7 @@ def _load(path):
                                         c.POINTER(c.c_int64)]
     L.sfm_gpu_debug_set_knn_variant.argtypes = [vp, c.c_int]
     L.sfm_gpu_debug_redo_count.argtypes = [vp, vp]
+    L.sfm_gpu_debug_score_stamps.argtypes = [vp, vp, c.c_int, vp]
     L.sfm_gpu_debug_poison_lds.argtypes = [vp, c.c_uint32]
     L.sfm_gpu_debug_copy_records.argtypes = [vp, vp, c.c_size_t]
     L.sfm_gpu_debug_sweep_stamps.argtypes = [vp, vp, c.c_int]

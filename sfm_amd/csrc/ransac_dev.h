@@ -138,6 +138,8 @@ hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_pro
 hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_prob, int cap, int model, int hyp0,
                                int n_hyp, bool staged, int filter_mode, int prune_mode);
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap);
+// timing build: per-wavefront stamps of the scoring launches since the last call (hipErrorNotSupported otherwise)
+hipError_t read_score_stamps(unsigned long long* out, int n_max, int* count);
 // Adaptive mode: replays RANSACPointSetRegistrator::run's loop over the counts of
 // sample rows [row0, row0 + nrows) on the device (one wavefront per problem); a
 // problem's progress lives in its result block (R_ITERS, R_NINL, R_HYP, R_Q,

@@ -1637,7 +1637,8 @@ constexpr int SCORE_QCAP = 40;  // tests a lane can park per span before it fall
 // not make the other 63 wait at every such point.
 template <int MODEL>
 __device__ __forceinline__ int score_span(const RansacProb& pb, const ScoreLane<MODEL>& m, int i0, int i1,
-                                          unsigned short* parked, int lane, int use_filter)
+                                          unsigned short* parked, int lane, int use_filter,
+                                          unsigned long long* t_after_filter = nullptr)
 {
     typedef const double __attribute__((address_space(4))) cdouble;
     typedef const f2v __attribute__((address_space(4))) cf2v;
@@ -1704,6 +1705,9 @@ __device__ __forceinline__ int score_span(const RansacProb& pb, const ScoreLane<
             }
         }
     }
+#ifdef SFM_GPU_TIMING_BUILD
+    if (t_after_filter) *t_after_filter = __builtin_amdgcn_s_memrealtime();
+#endif
     // whatever is left needs the double-precision coefficients
     if (__builtin_amdgcn_ballot_w64(i < i1 || n_parked > 0) != 0ull) {
         double M[9];
@@ -1732,6 +1736,45 @@ constexpr int SCORE_WAVES = 1;  // independent wavefronts per workgroup
 // next stage in result[live_slot + 1].  The pieces of a stretch are then at
 // least SCORE_MIN_PIECE points long.
 constexpr int SCORE_MIN_PIECE = 128;
+// Timing build only: stamps of the scoring wavefronts that reach their end, four 64-bit words each
+// (scripts/experiments/score_residency.py): realtime counter (100 MHz) at entry; at exit; hardware id (16 bits) |
+// XCC id << 16 | ticks from entry to "models known to be live" << 32 | to "model and filter set up" << 48;
+// launch tag (32 bits) | ticks from entry to the end of the float32 loop << 32.
+#ifdef SFM_GPU_TIMING_BUILD
+constexpr unsigned SCORE_STAMPS = 1u << 18;
+__device__ unsigned long long g_score_stamps[SCORE_STAMPS * 4];
+__device__ unsigned g_score_stamp_count[64];  // slot = 64 * count[b] + b, b = workgroup % 64: no queue on one counter
+#define SFM_SCORE_T0()                                                       \
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();   \
+    unsigned long long stamp_tA = stamp_t0, stamp_tB = stamp_t0, stamp_tC = stamp_t0
+#define SFM_SCORE_MARK(v) v = __builtin_amdgcn_s_memrealtime()
+#define SFM_SCORE_TC &stamp_tC
+#define SFM_SCORE_STAMP(tag)                                                                                   \
+    do {                                                                                                       \
+        if ((threadIdx.x & 63) == 0) {                                                                         \
+            const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);              \
+            const unsigned slot_ = 64u * atomicAdd(&g_score_stamp_count[lin_ & 63u], 1u) + (lin_ & 63u);       \
+            if (slot_ < SCORE_STAMPS) {                                                                        \
+                unsigned hw_, xcc_;                                                                            \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                              \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                            \
+                g_score_stamps[4 * slot_] = stamp_t0;                                                          \
+                g_score_stamps[4 * slot_ + 1] = __builtin_amdgcn_s_memrealtime();                              \
+                g_score_stamps[4 * slot_ + 2] = (unsigned long long)(hw_ & 0xFFFFu) |                          \
+                                                ((unsigned long long)(xcc_ & 0xFu) << 16) |                    \
+                                                (((stamp_tA - stamp_t0) & 0xFFFFull) << 32) |                  \
+                                                (((stamp_tB - stamp_t0) & 0xFFFFull) << 48);                   \
+                g_score_stamps[4 * slot_ + 3] =                                                                \
+                    (unsigned long long)(unsigned)(tag) | (((stamp_tC - stamp_t0) & 0xFFFFull) << 32);         \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
+#else
+#define SFM_SCORE_T0() do { } while (0)
+#define SFM_SCORE_MARK(v) do { } while (0)
+#define SFM_SCORE_TC nullptr
+#define SFM_SCORE_STAMP(tag) do { } while (0)
+#endif
 template <int MODEL, bool STRIDED>
 __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const RansacProb* __restrict__ probs, int chunk_pts_arg,
                                                           int use_filter, int slot_begin, int slot_end,
@@ -1742,6 +1785,7 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
     // over the whole chip (consecutive workgroups are placed on the same compute unit until it
     // is full: live groups side by side in the grid would share a few units while the rest idle).
     // The opening stretch (-2: this order, no cuts) gains from it as well.
+    SFM_SCORE_T0();
     const bool by_group = !STRIDED && (live_slot >= 0 || live_slot == -2);  // -2: that grid order, no cuts
     const unsigned bx = by_group ? blockIdx.z : blockIdx.x, by = blockIdx.y, bz = by_group ? blockIdx.x : blockIdx.z;
     const unsigned gdx = by_group ? gridDim.z : gridDim.x;
@@ -1777,16 +1821,19 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
             if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
             if (by == 0 && lane == 0) atomicMax(&pb.result[live_slot + 1], g0 / 64 + 1);
         }
+        SFM_SCORE_MARK(stamp_tA);
         ScoreLane<MODEL> m;
         m.load(pb, e, R);
+        SFM_SCORE_MARK(stamp_tB);
         int cnt = 0;
         for (int i0 = pts_begin + by * chunk_pts; i0 < n; i0 += gridDim.y * chunk_pts) {
-            cnt += score_span<MODEL>(pb, m, i0, min(n, i0 + chunk_pts), parked, lane, use_filter);
+            cnt += score_span<MODEL>(pb, m, i0, min(n, i0 + chunk_pts), parked, lane, use_filter, SFM_SCORE_TC);
             if (!STRIDED) break;  // the grid covers every chunk: straight-line code
         }
         if (active && cnt != 0) atomicAdd(&pb.counts[e], cnt);
         if (!STRIDED) break;
     }
+    SFM_SCORE_STAMP(live_slot);
 }
 
 // Between the opening stretch [0, R_S0), on which every listed model has been
@@ -2512,6 +2559,36 @@ hipError_t launch_ransac_replay(hipStream_t s, const RansacProb* probs, int n_pr
     hipLaunchKernelGGL(ransac_replay_kernel, dim3(n_prob), dim3(64), 0, s, probs, row0, nrows, max_iters, confidence);
     return hipGetLastError();
 }
+hipError_t read_score_stamps(unsigned long long* out, int n_max, int* count)
+{
+#ifdef SFM_GPU_TIMING_BUILD
+    unsigned per[64];
+    hipError_t e = hipMemcpyFromSymbol(per, HIP_SYMBOL(g_score_stamp_count), sizeof(per));
+    if (e != hipSuccess) return e;
+    // slots are 64 * k + b for k < per[b]: copy the covered prefix and keep the slots that were written
+    unsigned hi = 0;
+    for (int b = 0; b < 64; ++b) hi = std::max(hi, per[b]);
+    const unsigned span = std::min(64u * hi, SCORE_STAMPS);
+    std::vector<unsigned long long> all((size_t)span * 4);
+    if (span) {
+        e = hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(g_score_stamps), all.size() * 8);
+        if (e != hipSuccess) return e;
+    }
+    int c = 0;
+    for (unsigned slot = 0; slot < span && c < n_max; ++slot)
+        if (slot / 64u < per[slot % 64u]) {
+            for (int w = 0; w < 4; ++w) out[4 * (size_t)c + w] = all[4 * (size_t)slot + w];
+            ++c;
+        }
+    *count = c;
+    unsigned zero[64] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_score_stamp_count), zero, sizeof(zero));
+#else
+    (void)out; (void)n_max; (void)count;
+    return hipErrorNotSupported;
+#endif
+}
+
 hipError_t launch_ransac_mask(hipStream_t s, const RansacProb* probs, int n_prob, int cap)
 {
     hipLaunchKernelGGL(ransac_mask_kernel, dim3((cap + 255) / 256 > 0 ? (cap + 255) / 256 : 1, n_prob),

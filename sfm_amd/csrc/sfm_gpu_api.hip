@@ -676,6 +676,20 @@ int sfm_gpu_debug_sweep_stamps(sfm_gpu_ctx* ctx, uint64_t* out, int n_wg)
     return SFM_GPU_OK;
 }
 
+// Timing build only: stamps of the scoring wavefronts since the last call (4 words each).
+int sfm_gpu_debug_score_stamps(sfm_gpu_ctx* ctx, uint64_t* out, int n_max, int32_t* count)
+{
+    if (!ctx || !out || !count || n_max < 0) return SFM_GPU_ERR_ARG;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int c = 0;
+    const hipError_t e = read_score_stamps((unsigned long long*)out, n_max, &c);
+    if (e == hipErrorNotSupported) return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "stamps exist in the timing build only");
+    SFM_HIP(ctx, e);
+    *count = c;
+    return SFM_GPU_OK;
+}
+
 // Number of queries the last k-NN call on this context sent through the
 // exhaustive float-ranked pass (first job of the call).
 int sfm_gpu_debug_redo_count(sfm_gpu_ctx* ctx, int32_t* out)
