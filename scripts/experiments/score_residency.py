@@ -44,6 +44,7 @@ tags = (st[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.uint32).astype(np.int32).ast
 dA = ((st[:, 2] >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.float64) / 100.0   # entry -> models known to be live
 dB = ((st[:, 2] >> np.uint64(48)) & np.uint64(0xFFFF)).astype(np.float64) / 100.0   # entry -> model and filter set up
 dC = ((st[:, 3] >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.float64) / 100.0   # entry -> float32 loop done
+cyc = ((st[:, 3] >> np.uint64(48)) & np.uint64(0xFFFF)).astype(np.float64) * 16.0    # shader cycles of the wavefront's life
 for tag in sorted(set(tags.tolist())):
     s = st[tags == tag]
     t0, t1 = s[:, 0].astype(np.int64), s[:, 1].astype(np.int64)
@@ -80,3 +81,4 @@ for tag in sorted(set(tags.tolist())):
     sel = tags == tag
     print("         phases (median us from entry): live check %.1f, model set up %.1f, float32 loop done %.1f, end %.1f"
           % (np.median(dA[sel]), np.median(dB[sel]), np.median(dC[sel]), np.median(life)))
+    print("         shader clock over the wavefronts' lives: median %.0f MHz" % np.median(cyc[sel] / life))

@@ -1735,17 +1735,21 @@ constexpr int SCORE_WAVES = 1;  // independent wavefronts per workgroup
 // can hold anything else, and the wavefronts that go on record the same for the
 // next stage in result[live_slot + 1].  The pieces of a stretch are then at
 // least SCORE_MIN_PIECE points long.
+// (measured on the bench, ms per step: pieces of 64 / 128 / 256 / 512 points 0.861 / 0.852 / 0.873 / 0.923;
+// 8192 / 16384 / 32768 items 0.887 / 0.852 / 0.852)
 constexpr int SCORE_MIN_PIECE = 128;
+constexpr int SCORE_STAGE_ITEMS = 16384;  // wavefronts a stage launch may use over the batch when the list is short
 // Timing build only: stamps of the scoring wavefronts that reach their end, four 64-bit words each
 // (scripts/experiments/score_residency.py): realtime counter (100 MHz) at entry; at exit; hardware id (16 bits) |
 // XCC id << 16 | ticks from entry to "models known to be live" << 32 | to "model and filter set up" << 48;
-// launch tag (32 bits) | ticks from entry to the end of the float32 loop << 32.
+// launch tag (32 bits) | ticks from entry to the end of the float32 loop << 32 | shader cycles of its life / 16 << 48.
 #ifdef SFM_GPU_TIMING_BUILD
 constexpr unsigned SCORE_STAMPS = 1u << 18;
 __device__ unsigned long long g_score_stamps[SCORE_STAMPS * 4];
 __device__ unsigned g_score_stamp_count[64];  // slot = 64 * count[b] + b, b = workgroup % 64: no queue on one counter
 #define SFM_SCORE_T0()                                                       \
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();   \
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime();       \
     unsigned long long stamp_tA = stamp_t0, stamp_tB = stamp_t0, stamp_tC = stamp_t0
 #define SFM_SCORE_MARK(v) v = __builtin_amdgcn_s_memrealtime()
 #define SFM_SCORE_TC &stamp_tC
@@ -1765,7 +1769,8 @@ __device__ unsigned g_score_stamp_count[64];  // slot = 64 * count[b] + b, b = w
                                                 (((stamp_tA - stamp_t0) & 0xFFFFull) << 32) |                  \
                                                 (((stamp_tB - stamp_t0) & 0xFFFFull) << 48);                   \
                 g_score_stamps[4 * slot_ + 3] =                                                                \
-                    (unsigned long long)(unsigned)(tag) | (((stamp_tC - stamp_t0) & 0xFFFFull) << 32);         \
+                    (unsigned long long)(unsigned)(tag) | (((stamp_tC - stamp_t0) & 0xFFFFull) << 32) |        \
+                    ((((__builtin_amdgcn_s_memtime() - stamp_c0) >> 4) & 0xFFFFull) << 48);                    \
             }                                                                                                  \
         }                                                                                                      \
     } while (0)
@@ -1780,30 +1785,45 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
                                                           int use_filter, int slot_begin, int slot_end,
                                                           int list_limit, int live_slot)
 {
-    // live_slot >= 0 or -2: grid = (problems, pieces, groups), so that the groups at the head of the
-    // ordered list, the only ones with work in the later stages, are dispatched first and spread
-    // over the whole chip (consecutive workgroups are placed on the same compute unit until it
-    // is full: live groups side by side in the grid would share a few units while the rest idle).
-    // The opening stretch (-2: this order, no cuts) gains from it as well.
+    // live_slot == -2 (the opening stretch): grid = (problems, pieces, groups).  Consecutive
+    // workgroups are placed on the same compute unit until it is full, so problems vary fastest
+    // and a problem's groups are spread over the whole chip.
+    // live_slot >= 0 (a stage): grid = (problems, work items).  Only the result[live_slot] groups
+    // at the head of the ordered list can have work, so the problem's items go to them alone:
+    // item -> (group, piece), pieces as short as SCORE_MIN_PIECE points when the items allow it,
+    // group-major, so that the wavefronts with work are dispatched first and side by side in the
+    // grid only across problems.
     SFM_SCORE_T0();
-    const bool by_group = !STRIDED && (live_slot >= 0 || live_slot == -2);  // -2: that grid order, no cuts
-    const unsigned bx = by_group ? blockIdx.z : blockIdx.x, by = blockIdx.y, bz = by_group ? blockIdx.x : blockIdx.z;
+    const bool stage = !STRIDED && live_slot >= 0;
+    const bool by_group = !STRIDED && live_slot == -2;
+    unsigned bx = by_group ? blockIdx.z : blockIdx.x, by = blockIdx.y;
+    const unsigned bz = (by_group || stage) ? blockIdx.x : blockIdx.z;
     const unsigned gdx = by_group ? gridDim.z : gridDim.x;
     const RansacProb pb = probs[bz];
     const int nlist = min(__builtin_amdgcn_readfirstlane(pb.result[R_NLIST]), list_limit);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (((int)bx * SCORE_WAVES + wv) * 64 >= nlist) return;
-    if (!STRIDED && live_slot >= 0 &&
-        (int)bx * SCORE_WAVES + wv >= __builtin_amdgcn_readfirstlane(pb.result[live_slot]))
-        return;
     const int pts_begin = slot_begin >= 0 ? __builtin_amdgcn_readfirstlane(pb.result[slot_begin]) : 0;
     const int n_all = __builtin_amdgcn_readfirstlane(*pb.n_ptr);
     int n = n_all;
     if (slot_end >= 0) n = min(n, __builtin_amdgcn_readfirstlane(pb.result[slot_end]));
-    // chunk_pts_arg <= 0: the problem's stretch in equal pieces, one per grid row
-    int chunk_pts = chunk_pts_arg > 0 ? chunk_pts_arg
+    int chunk_pts;
+    if (stage) {
+        const int live = __builtin_amdgcn_readfirstlane(pb.result[live_slot]);
+        const int len = n - pts_begin;
+        if (live <= 0 || len <= 0) return;
+        // (the grid has at least as many items as the list has groups, hence >= live)
+        const int most = (len + SCORE_MIN_PIECE - 1) / SCORE_MIN_PIECE;
+        const int pieces = max(1, min(most, (int)gridDim.y / live));
+        chunk_pts = ((len + pieces - 1) / pieces + 3) & ~3;
+        bx = blockIdx.y / (unsigned)pieces;
+        by = blockIdx.y - bx * (unsigned)pieces;
+        if ((int)bx >= live) return;
+    } else {
+        // chunk_pts_arg <= 0: the problem's stretch in equal pieces, one per grid row
+        chunk_pts = chunk_pts_arg > 0 ? chunk_pts_arg
                                       : (((max(n - pts_begin, 0) + (int)gridDim.y - 1) / (int)gridDim.y + 3) & ~3);
-    if (!STRIDED && live_slot >= 0) chunk_pts = max(chunk_pts, SCORE_MIN_PIECE);
+    }
+    if (((int)bx * SCORE_WAVES + wv) * 64 >= nlist) return;
     if (pts_begin + (int)by * chunk_pts >= n) return;  // stage boundaries and chunk_pts are multiples of 4
     const int lane = threadIdx.x & 63;
     __shared__ unsigned short parked_all[SCORE_WAVES * SCORE_QCAP * 64];
@@ -1812,9 +1832,9 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
     for (int g0 = (bx * SCORE_WAVES + wv) * 64; g0 < nlist; g0 += gdx * SCORE_WAVES * 64) {
         const bool active = g0 + lane < nlist;
         // the stages read the ordered list where ransac_sortplan_kernel left it
-        const int32_t* lst = (!STRIDED && live_slot >= 0) ? pb.list2 + __builtin_amdgcn_readfirstlane(pb.result[R_TOP]) : pb.list;
+        const int32_t* lst = stage ? pb.list2 + __builtin_amdgcn_readfirstlane(pb.result[R_TOP]) : pb.list;
         const int e = lst[active ? g0 + lane : g0];
-        if (!STRIDED && live_slot >= 0) {
+        if (stage) {
             // (every piece of the group sees the same counts: the stage before is complete)
             const int bound = __builtin_amdgcn_readfirstlane(pb.result[R_BOUND]);
             const bool alive = active && pb.counts[e] + (n_all - pts_begin) >= bound;
@@ -2002,7 +2022,12 @@ __global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb*
             pb.result[R_BOUND] = bound;
             pb.result[R_NLIST] = nlist - top;
             pb.result[R_TOP] = top;
-            pb.result[R_LIVE] = (nlist - top + 63) / 64;
+            // The list is in descending order of the opening counts and hist[c] now is
+            // the number of models with at least c: the models the first stage cannot
+            // rule out at the door (count + points left >= bound) are a prefix of it.
+            const int need = bound - (n - s0);
+            const int reach = need <= 0 ? nlist : (need > SCORE_OPENING ? 0 : hist[need]);
+            pb.result[R_LIVE] = (max(reach - top, 0) + 63) / 64;
             auto up128 = [](int v) { return (v + 127) / 128 * 128; };
             {
                 // A model that misses nearly every point falls out of reach once its misses
@@ -2479,7 +2504,9 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     auto score = [&](int chunk_pts, int slot_begin, int slot_end, int chunks, unsigned gx, int list_limit,
                      bool strided, int live_slot = -1) {
         const unsigned gw = (gx + SCORE_WAVES - 1) / SCORE_WAVES;
-        const dim3 grid = (live_slot >= 0 || live_slot == -2) ? dim3(n_prob, chunks, gw) : dim3(gw, chunks, n_prob);
+        // (a stage, live_slot >= 0: `chunks` work items per problem, shared out on the device)
+        const dim3 grid = live_slot >= 0 ? dim3(n_prob, chunks, 1)
+                                         : (live_slot == -2 ? dim3(n_prob, chunks, gw) : dim3(gw, chunks, n_prob));
         const dim3 block(SCORE_WAVES * 64);
         const int f = filter_mode;
         if (model == SFM_GPU_MODEL_ESSENTIAL) {
@@ -2514,12 +2541,13 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
     if (staged && prune_mode == 1 && cap >= 1024) {
         score(SCORE_OPENING / 2, -1, R_S0, 2, groups, INT_MAX, false, -2);  // (group-major: 75 against 68 us)
         hipLaunchKernelGGL(ransac_sortplan_kernel, dim3(n_prob), dim3(1024), 0, s, probs);
-        // pieces per stage: what a stage of the largest problem needs at 128 points a piece
-        const int p1 = std::max(1, std::min(8, cap / 4 / 128)), p4 = std::max(1, std::min(16, cap / 512));
-        score(0, R_S0, R_S1, p1, groups, INT_MAX, false, R_LIVE);
-        score(0, R_S1, R_MID, std::max(2, p4 / 8), groups, INT_MAX, false, R_LIVE + 1);
-        score(0, R_MID, R_S3, std::max(4, p4 / 4), groups, INT_MAX, false, R_LIVE + 2);
-        score(0, R_S3, -1, p4, groups, INT_MAX, false, R_LIVE + 3);
+        // work items per problem and stage: one per group of the list at least (every group
+        // may still be in play), and enough over the batch to fill the chip when few are
+        const int items = std::max((int)groups, std::min(1024, SCORE_STAGE_ITEMS / n_prob));
+        score(0, R_S0, R_S1, items, groups, INT_MAX, false, R_LIVE);
+        score(0, R_S1, R_MID, items, groups, INT_MAX, false, R_LIVE + 1);
+        score(0, R_MID, R_S3, items, groups, INT_MAX, false, R_LIVE + 2);
+        score(0, R_S3, -1, items, groups, INT_MAX, false, R_LIVE + 3);
     } else if (staged && prune_mode >= 2 && cap >= 1024) {
         // Stages sized from the opening stretch's best count, the list compacted at a
         // cut between them (prune_mode 2: two cuts, 3: one).
