@@ -1724,7 +1724,10 @@ __device__ __forceinline__ int score_span(const RansacProb& pb, const ScoreLane<
 // grid = (groups of 64 models, point chunks from chunk0 on, problems); a
 // workgroup strides over further groups / chunks when the grid is smaller than
 // the work, keeping its models in registers from chunk to chunk.
-constexpr int SCORE_WAVES = 1;  // independent wavefronts per workgroup
+#ifndef SFM_SCORE_WAVES
+#define SFM_SCORE_WAVES 1
+#endif
+constexpr int SCORE_WAVES = SFM_SCORE_WAVES;  // independent wavefronts per workgroup
 // The points a launch covers are [result[slot_begin], min(n, result[slot_end])) of
 // its problem (a slot < 0 stands for 0 / n), the models the first
 // min(R_NLIST, list_limit) of the list.
@@ -1813,23 +1816,25 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
         if (live <= 0 || len <= 0) return;
         // (the grid has at least as many items as the list has groups, hence >= live)
         const int most = (len + SCORE_MIN_PIECE - 1) / SCORE_MIN_PIECE;
-        const int pieces = max(1, min(most, (int)gridDim.y / live));
+        const int pieces = max(1, min(most, (int)gridDim.y * SCORE_WAVES / live));
         chunk_pts = ((len + pieces - 1) / pieces + 3) & ~3;
-        bx = blockIdx.y / (unsigned)pieces;
-        by = blockIdx.y - bx * (unsigned)pieces;
+        const unsigned item = blockIdx.y * SCORE_WAVES + wv;
+        bx = item / (unsigned)pieces;
+        by = item - bx * (unsigned)pieces;
         if ((int)bx >= live) return;
+        if ((int)bx * 64 >= nlist) return;
     } else {
         // chunk_pts_arg <= 0: the problem's stretch in equal pieces, one per grid row
         chunk_pts = chunk_pts_arg > 0 ? chunk_pts_arg
                                       : (((max(n - pts_begin, 0) + (int)gridDim.y - 1) / (int)gridDim.y + 3) & ~3);
     }
-    if (((int)bx * SCORE_WAVES + wv) * 64 >= nlist) return;
+    if (!stage && ((int)bx * SCORE_WAVES + wv) * 64 >= nlist) return;
     if (pts_begin + (int)by * chunk_pts >= n) return;  // stage boundaries and chunk_pts are multiples of 4
     const int lane = threadIdx.x & 63;
     __shared__ unsigned short parked_all[SCORE_WAVES * SCORE_QCAP * 64];
     unsigned short* parked = parked_all + wv * (SCORE_QCAP * 64);
     const float R = __int_as_float(__builtin_amdgcn_readfirstlane(pb.result[R_MAXABS]));
-    for (int g0 = (bx * SCORE_WAVES + wv) * 64; g0 < nlist; g0 += gdx * SCORE_WAVES * 64) {
+    for (int g0 = (stage ? bx : bx * SCORE_WAVES + wv) * 64; g0 < nlist; g0 += gdx * SCORE_WAVES * 64) {
         const bool active = g0 + lane < nlist;
         // the stages read the ordered list where ransac_sortplan_kernel left it
         const int32_t* lst = stage ? pb.list2 + __builtin_amdgcn_readfirstlane(pb.result[R_TOP]) : pb.list;
@@ -2505,7 +2510,7 @@ hipError_t launch_ransac_score(hipStream_t s, const RansacProb* probs, int n_pro
                      bool strided, int live_slot = -1) {
         const unsigned gw = (gx + SCORE_WAVES - 1) / SCORE_WAVES;
         // (a stage, live_slot >= 0: `chunks` work items per problem, shared out on the device)
-        const dim3 grid = live_slot >= 0 ? dim3(n_prob, chunks, 1)
+        const dim3 grid = live_slot >= 0 ? dim3(n_prob, (chunks + SCORE_WAVES - 1) / SCORE_WAVES, 1)
                                          : (live_slot == -2 ? dim3(n_prob, chunks, gw) : dim3(gw, chunks, n_prob));
         const dim3 block(SCORE_WAVES * 64);
         const int f = filter_mode;
