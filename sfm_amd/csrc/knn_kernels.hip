@@ -947,9 +947,11 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
             const int qi = s_list[it];
             const int q = wg.qblock * RESCAN_QPW + qi;
             const u64 c1 = s_c[qi][0], c2 = s_c[qi][1];
-            const bool have_b = c2 != NONE;
+            // (a query without any record -- no train rows, or a sweep run with its digest
+            // switched off for timing -- has no group to gather: row 0 is read and ignored)
+            const bool have_a = c1 != NONE, have_b = c2 != NONE;
             const uint32_t ida = (uint32_t)c1;
-            const int base_a = (int)(ida >> SB) * UROWS + 4 * (int)(ida & ((1u << SB) - 1u));
+            const int base_a = have_a ? (int)(ida >> SB) * UROWS + 4 * (int)(ida & ((1u << SB) - 1u)) : 0;
             const v4i qv = *(const v4i*)(job.q_desc + (size_t)q * DIM + sg * 16);
             // candidate c = 2 * it2 + rq of the group is row base_a + JSTRIDE * (c >> 2) + (c & 3)
             v4i tv[8];
@@ -1004,7 +1006,7 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
             const int row1 = __shfl(row, ((p1 & 1) << 3) | (p1 >> 1), 16);
             if (l16 == 0) {
                 bool done = false;
-                if (have_b && e1 != 0xFFFFFFFFu) {
+                if (have_a && have_b && e1 != 0xFFFFFFFFu) {
                     const int32_t dA1 = (int32_t)(e1 >> 5);
                     const int32_t dA2 = e2 != 0xFFFFFFFFu ? (int32_t)(e2 >> 5) : 0x7FFFFFFF;
                     const int32_t L = qn - 2 * KEY_OFFSET + 2 * (int32_t)(uint32_t)(c2 >> 32);

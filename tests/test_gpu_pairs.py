@@ -288,6 +288,38 @@ def test_verdicts_that_hang_on_one_unit_of_squared_distance(gpu_ctx, oracle):
         im.close()
 
 
+def test_queries_without_any_sweep_record_give_no_match():
+    """bench.py's ceiling measurement runs the pipeline on a sweep whose digest is
+    switched off (timing build): every record then says "no group".  The
+    neighbour extraction has to treat such a query as one without neighbours -- it
+    must not turn the empty record into a row to gather."""
+    try:
+        tctx = matcher.Context(0, timing_build=True)
+    except OSError:
+        pytest.skip("no timing build of the library in this tree")
+    rng = np.random.default_rng(77)
+    images = []
+    for v in range(4):
+        n = 700 + 64 * v
+        d = synth.sift_like(n, 900 + v)
+        kp = np.stack([rng.uniform(0, synth.IMG_W, n), rng.uniform(0, synth.IMG_H, n)], 1).astype(np.float32)
+        images.append(matcher.Image(tctx, d, kp))
+    pairs = np.array([[0, 1], [2, 3], [1, 2]], np.int32)
+    kw = dict(ratio=0.7, model=matcher.MODEL_FUNDAMENTAL, mode=matcher.RANSAC_FIXED, prob=0.99, threshold=3.0,
+              n_hyp=64)
+    g_ref, i_ref = matcher.match_pairs(tctx, images, pairs, None, **kw)
+    assert g_ref.sum() >= 0
+    tctx.check(tctx._L.sfm_gpu_debug_set_knn_variant(tctx.handle, 4 + 16 * 7))   # MFMAs and fragment reads only
+    g, i = matcher.match_pairs(tctx, images, pairs, None, **kw)
+    assert (g == 0).all() and (i == 0).all()
+    tctx.check(tctx._L.sfm_gpu_debug_set_knn_variant(tctx.handle, -1))
+    g2, i2 = matcher.match_pairs(tctx, images, pairs, None, **kw)
+    assert (g2 == g_ref).all() and (i2 == i_ref).all()
+    for im in images:
+        im.close()
+    tctx.close()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.uint8])
 def test_images_prepared_in_device_memory_match_owned_images(gpu_ctx, dtype):
     """Descriptors that already sit in device memory (float rows as
