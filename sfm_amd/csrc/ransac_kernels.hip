@@ -1621,8 +1621,11 @@ struct ScoreLane {
 #pragma unroll
         for (int i = 0; i < 9; ++i) M[i] = Mg[i];
         fc = make_filter<MODEL>(M, (double)R, pb.tf);
+        // (a model the filter refuses -- infinite slacks -- gets zero coefficients: every
+        // filter value of it is then finite, +inf or -inf, never a NaN)
+        const bool refused = fc.kin[0] == __builtin_inff();
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Mf[k] = (float)M[k];
+        for (int k = 0; k < 9; ++k) Mf[k] = refused ? 0.f : (float)M[k];
     }
 };
 
@@ -1689,18 +1692,30 @@ __device__ __forceinline__ int score_span(const RansacProb& pb, const ScoreLane<
             const PairTerms tA = filter_terms<MODEL>(m.Mf, cur[0], cur[2], cur[4], cur[6]);
             const PairTerms tB = filter_terms<MODEL>(m.Mf, cur[1], cur[3], cur[5], cur[7]);
             const f2v hinA = filter_h_in(tA, m.fc), hinB = filter_h_in(tB, m.fc);
-            const bool in0 = hinA.x <= 0.f, in1 = hinA.y <= 0.f, in2 = hinB.x <= 0.f, in3 = hinB.y <= 0.f;
-            cnt += (in0 ? 1 : 0) + (in1 ? 1 : 0) + (in2 ? 1 : 0) + (in3 ? 1 : 0);
-            // the outlier test is only needed where a lane could not prove "in"
-            if (__builtin_amdgcn_ballot_w64(!(in0 && in1 && in2 && in3)) != 0ull) {
-                const f2v houtA = filter_h_out(tA, m.fc), houtB = filter_h_out(tB, m.fc);
-                const bool u0 = !(in0 || houtA.x >= 0.f), u1 = !(in1 || houtA.y >= 0.f);
-                const bool u2 = !(in2 || houtB.x >= 0.f), u3 = !(in3 || houtB.y >= 0.f);
-                if (u0 || u1 || u2 || u3) {
-                    if (u0) park(i);
-                    if (u1) park(i + 1);
-                    if (u2) park(i + 2);
-                    if (u3) park(i + 3);
+            const f2v houtA = filter_h_out(tA, m.fc), houtB = filter_h_out(tB, m.fc);
+            // Verdicts from the sign bits, without compares or lane masks (the loop is
+            // bound by the instructions a wavefront issues): h_in < 0 proves an inlier,
+            // h_out < 0 is an outlier not proven.  Zeros read as "not proven" on either
+            // side, which only sends the test to the double-precision pass, and no value
+            // here is a NaN: the coordinates are finite (the caller checks the problem's
+            // largest one), and a model whose terms could overflow has its float32
+            // coefficients set to zero and infinite slacks (ScoreLane::load).
+            // bit 3 = point i ... bit 0 = point i + 3
+            unsigned sin = __float_as_uint(hinA.x) >> 31;
+            sin = __builtin_amdgcn_alignbit(sin, __float_as_uint(hinA.y), 31);
+            sin = __builtin_amdgcn_alignbit(sin, __float_as_uint(hinB.x), 31);
+            sin = __builtin_amdgcn_alignbit(sin, __float_as_uint(hinB.y), 31);
+            cnt += __builtin_popcount(sin);
+            unsigned sout = __float_as_uint(houtA.x) >> 31;
+            sout = __builtin_amdgcn_alignbit(sout, __float_as_uint(houtA.y), 31);
+            sout = __builtin_amdgcn_alignbit(sout, __float_as_uint(houtB.x), 31);
+            sout = __builtin_amdgcn_alignbit(sout, __float_as_uint(houtB.y), 31);
+            unsigned doubt = sout & ~sin;
+            while (__builtin_amdgcn_ballot_w64(doubt != 0u) != 0ull) {  // in most steps some lane has one, hardly ever two
+                if (doubt != 0u) {
+                    const int b = 31 - __builtin_clz(doubt);
+                    park(i + 3 - b);
+                    doubt &= ~(1u << b);
                 }
             }
         }
@@ -1834,6 +1849,7 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
     __shared__ unsigned short parked_all[SCORE_WAVES * SCORE_QCAP * 64];
     unsigned short* parked = parked_all + wv * (SCORE_QCAP * 64);
     const float R = __int_as_float(__builtin_amdgcn_readfirstlane(pb.result[R_MAXABS]));
+    if (!(R < 1e18f)) use_filter = 0;  // coordinates that are huge, infinite or not numbers: double precision only
     for (int g0 = (stage ? bx : bx * SCORE_WAVES + wv) * 64; g0 < nlist; g0 += gdx * SCORE_WAVES * 64) {
         const bool active = g0 + lane < nlist;
         // the stages read the ordered list where ransac_sortplan_kernel left it

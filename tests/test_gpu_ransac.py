@@ -213,6 +213,43 @@ def test_scoring_filter_is_exact_on_near_threshold_points(gpu_ctx, oracle, full_
     assert 1500 + 200 < best < 6000 - 200
 
 
+@pytest.mark.parametrize("poison", ["big", "huge", "inf", "nan"])
+@pytest.mark.parametrize("model", [0, 1])
+def test_scoring_with_huge_or_non_finite_coordinates(gpu_ctx, oracle, full_counts, model, poison):
+    """A few correspondences whose coordinates are huge, infinite or not numbers
+    (none of them in a sample): the float32 filter reads its verdicts off sign
+    bits and must not be asked about such a problem; every count, the mask and
+    the winner are those of the double-precision loop."""
+    rng = np.random.default_rng(5)
+    p1, p2, _, _ = synth.two_view(2600, 91 + model, inlier_frac=0.8)
+    p1 = p1.astype(np.float32).astype(np.float64)
+    p2 = p2.astype(np.float32).astype(np.float64)
+    # "big" still passes for a coordinate the filter may see (< 1e18); its models' terms
+    # could overflow float32, so the filter refuses every model instead
+    bad = {"big": 1e17, "huge": 3e30, "inf": np.inf, "nan": np.nan}[poison]
+    rows = rng.permutation(np.arange(2000, 2600))[:24]
+    p1[rows[:8], 0] = bad
+    p2[rows[8:16], 1] = -bad
+    p1[rows[16:], 1] = bad
+    p2[rows[16:], 0] = bad
+    m = 5 if model == 0 else 7
+    thr = 1.0 if model == 0 else 3.0
+    K = synth.REF_K if model == 0 else None
+    table = np.stack([rng.permutation(2000)[:m] for _ in range(96)]).astype(np.int32)
+    o = oracle.ransac(p1, p2, K, model=model, prob=0.99, threshold=thr, fixed_count=len(table),
+                      sample_table=table, want_counts=True)
+    if model == 0:
+        M, mask, r = matcher.findEssentialMat(gpu_ctx, p1, p2, K, prob=0.99, threshold=thr,
+                                              mode=matcher.RANSAC_FIXED, sample_table=table)
+    else:
+        M, mask, r = matcher.findFundamentalMat(gpu_ctx, p1, p2, ransacReprojThreshold=thr, confidence=0.99,
+                                                mode=matcher.RANSAC_FIXED, sample_table=table)
+    _, _, counts, _ = _dump(gpu_ctx, len(table), m)
+    assert (counts == o["counts"]).all()
+    assert (mask == o["mask"]).all() and r["n_inliers"] == o["n_inliers"] and r["ok"] == o["ok"]
+    assert o["n_inliers"] > 1000 and not mask[rows].any()
+
+
 @pytest.mark.parametrize("prune_mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("model", [0, 1])
 @pytest.mark.parametrize("seed,n,frac", [(31, 400, 0.9), (32, 513, 0.5), (33, 3300, 0.93), (34, 3300, 0.35),
