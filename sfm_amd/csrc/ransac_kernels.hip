@@ -1886,7 +1886,12 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
 //    a lower bound of the winner's count,
 //  * sets the ends R_S1, R_MID, R_S3 of the stages that follow and the count of
 //    groups the first of them has to look at (R_LIVE).
-constexpr int SORT_TOP = 8;
+// (measured on the bench, ms per step: 1 / 2 / 4 / 8 / 16 models completed 0.835 / 0.830 / 0.833 / 0.8375 / 0.849:
+// few models finish sooner, many raise the bound a little)
+#ifndef SFM_SORT_TOP
+#define SFM_SORT_TOP 2
+#endif
+constexpr int SORT_TOP = SFM_SORT_TOP;  // a power of two, at most 16
 
 // Entries base + tid + 1024 k (k < 8) of a problem's list and their counts, all
 // loads of one kind issued together: these one-workgroup kernels are chains of
@@ -2012,10 +2017,11 @@ __global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb*
             if (eb[k] >= 0) place(eb[k], min(max(cb[k], 0), SCORE_OPENING));
     }
     __syncthreads();
-    // the best SORT_TOP, 128 threads each, over the points the opening has not seen
+    // the best SORT_TOP, 1024 / SORT_TOP threads each, over the points the opening has not seen
     const int top = min(SORT_TOP, nlist);
     {
-        const int t = tid >> 7, j = tid & 127;
+        constexpr int TPM = 1024 / SORT_TOP;  // threads per model
+        const int t = tid / TPM, j = tid % TPM;
         int add = 0;
         if (t < top) {
             const int et = s_top_e[t];
@@ -2023,7 +2029,7 @@ __global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb*
             double M[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) M[i] = Mg[i];
-            add = count_exact_strided(pb, M, s0 + j, 128, n);
+            add = count_exact_strided(pb, M, s0 + j, TPM, n);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) add += __shfl_xor(add, off);
@@ -2054,6 +2060,8 @@ __global__ void __launch_bounds__(1024) ransac_sortplan_kernel(const RansacProb*
                 // A model that misses nearly every point falls out of reach once its misses
                 // exceed n - bound: the first stage ends just past that, where most of the
                 // list stops; the later stages grow, as fewer and fewer models reach them.
+                // (three stages instead of four: 0.831-0.836 against 0.823 ms per step; other
+                // shares for the second and third stage, 1/10 + 1/4 or 1/6 + 1/2: no difference)
                 const int b1 = max(up128((int)(1.06 * (double)(n - bound)) + 16), s0 + 128);
                 const int b2 = b1 + up128(max(256, (n - b1) / 8));
                 const int b3 = b2 + up128(max(640, (n - b2) / 3));
