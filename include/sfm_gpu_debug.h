@@ -90,6 +90,11 @@ int sfm_gpu_debug_set_score_filter(sfm_gpu_ctx* ctx, int on);
  * in every mode. */
 int sfm_gpu_debug_set_score_prune(sfm_gpu_ctx* ctx, int on);
 
+/* Per context.  The seven-point elimination exists with one lane per hypothesis
+ * and with two lanes sharing a hypothesis (half the LDS per wavefront; same
+ * models bit for bit): -1 (default) picks by batch size, 0 / 1 force one / two. */
+int sfm_gpu_debug_set_solver_split(sfm_gpu_ctx* ctx, int mode);
+
 /* Environment, read once per process: SFM_GPU_ROCTX=1 brackets every stage of a
  * call (the names sfm_gpu_profile_query knows: "knn2_mfma", "knn_finalize",
  * "ratio_compact", "ransac_solve", "ransac_score", ...) in a rocTX range

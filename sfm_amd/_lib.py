@@ -128,6 +128,7 @@ def _load(path):
     L.sfm_gpu_debug_set_score_filter.argtypes = [vp, c.c_int]
     L.sfm_gpu_debug_pose_votes.argtypes = [vp, vp]
     L.sfm_gpu_debug_set_score_prune.argtypes = [vp, c.c_int]
+    L.sfm_gpu_debug_set_solver_split.argtypes = [vp, c.c_int]
     L.sfm_gpu_track_join.argtypes = [vp, vp, c.c_int, vp, c.c_int, vp, c.c_int, vp]
     L.sfm_gpu_track_join_sequence.argtypes = [vp, vp, vp, c.c_int, c.c_int, vp, c.c_int, vp]
     L.sfm_gpu_recover_pose.argtypes = [vp, vp, vp, vp, c.c_int, vp, c.c_double, vp, vp, vp, vp]

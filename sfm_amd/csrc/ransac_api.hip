@@ -174,7 +174,7 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
             // the seven-point solver draws its own rows unless the caller brought a table
             const int gen = (!custom_table_host && rp.model == SFM_GPU_MODEL_FUNDAMENTAL) ? nh : 0;
             ProfScope ps(ctx, "ransac_solve");
-            SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, rp.model, 0, nh, gen));
+            SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, rp.model, 0, nh, gen, ctx->solver_split));
         }
         {
             // staged scoring with an exact bound; the stages are sized per problem
@@ -211,7 +211,7 @@ int ransac_batch(sfm_gpu_ctx* ctx, std::vector<RansacProb>& probs, int cap, int 
         }
         {
             ProfScope ps(ctx, "ransac_solve");
-            SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, rp.model, done_rows, b));
+            SFM_HIP(ctx, launch_ransac_solve(s, dprobs, n_prob, rp.model, done_rows, b, 0, ctx->solver_split));
         }
         {
             ProfScope ps(ctx, "ransac_score");
@@ -252,6 +252,14 @@ int sfm_gpu_debug_set_score_filter(sfm_gpu_ctx* ctx, int on)
 #endif
     if (on < 0 || on > max_mode) return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "score filter mode %d", on);
     ctx->score_filter = on;
+    return SFM_GPU_OK;
+}
+
+int sfm_gpu_debug_set_solver_split(sfm_gpu_ctx* ctx, int mode)
+{
+    if (!ctx) return SFM_GPU_ERR_ARG;
+    if (mode < -1 || mode > 1) return ctx->fail(SFM_GPU_ERR_UNSUPPORTED, "solver split mode %d", mode);
+    ctx->solver_split = mode;
     return SFM_GPU_OK;
 }
 

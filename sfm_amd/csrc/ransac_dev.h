@@ -121,8 +121,9 @@ hipError_t launch_ransac_table(hipStream_t s, const RansacProb* probs, int n_pro
 hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int n_prob, int nrows);
 // gen_rows > 0 (fundamental model only, hyp0 = 0): the solver draws the fixed-count
 // sample rows itself instead of reading a table made by launch_ransac_table_fixed
+// split (seven-point only): -1 = one or two lanes per hypothesis by batch size, 0 / 1 = one / two
 hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp,
-                               int gen_rows = 0);
+                               int gen_rows = 0, int split = -1);
 // staged (fixed-count mode): every model is scored on an opening stretch of the
 // points; the list is then ordered by those counts and its best few are completed
 // (the largest of their counts bounds the winner's from below); four stages

@@ -1294,6 +1294,237 @@ __global__ void __launch_bounds__(64) ransac_solve7_kernel(const RansacProb* __r
     }
 }
 
+// The same elimination with LPH lanes per hypothesis (64 / LPH hypotheses per
+// wavefront, 63 * 8 * 64 / LPH bytes of LDS): the lanes of a hypothesis share its
+// matrix in LDS and split every loop of a step among them by index modulo LPH --
+// rows for the pivot search, the column swap and the elimination, columns for the
+// row swap and the division of the pivot row -- so that all lanes run one
+// instruction stream.  Every element goes through the operations of
+// seven_point_pencil in the same order; only who carries them out differs.  A
+// wavefront's LDS accesses are served in program order, so what one lane wrote is
+// there for its partner's next read; the fences keep the compiler from moving
+// accesses across those hand-overs.
+template <int LPH>
+__device__ __forceinline__ bool seven_point_pencil_split(double* sA, int h, int r, const float* m1, const float* m2,
+                                                         double* dst, bool writes)
+{
+    constexpr int HPW = 64 / LPH;
+#define SFM_SB2(i, j) sA[((i) * 9 + (j)) * HPW + h]
+    auto handover = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); };
+#pragma unroll
+    for (int k = 0; k < (7 + LPH - 1) / LPH; ++k) {
+        const int i = LPH * k + r;
+        if (i < 7) {
+            // (the lane's rows: points selected without indexing the arrays by a lane-dependent value)
+            float x0f = 0.f, y0f = 0.f, x1f = 0.f, y1f = 0.f;
+#pragma unroll
+            for (int q = 0; q < LPH; ++q)
+                if (LPH * k + q < 7 && r == q) {
+                    x0f = m1[2 * (LPH * k + q)];
+                    y0f = m1[2 * (LPH * k + q) + 1];
+                    x1f = m2[2 * (LPH * k + q)];
+                    y1f = m2[2 * (LPH * k + q) + 1];
+                }
+            const double x0 = x0f, y0 = y0f, x1 = x1f, y1 = y1f;
+            SFM_SB2(i, 0) = x1 * x0; SFM_SB2(i, 1) = x1 * y0; SFM_SB2(i, 2) = x1;
+            SFM_SB2(i, 3) = y1 * x0; SFM_SB2(i, 4) = y1 * y0; SFM_SB2(i, 5) = y1;
+            SFM_SB2(i, 6) = x0;      SFM_SB2(i, 7) = y0;      SFM_SB2(i, 8) = 1.0;
+        }
+    }
+    handover();
+    unsigned long long perm = 0x876543210ull;
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        // first maximum in row-major scan order: every lane over its rows, then across the lanes
+        int bi = p, bj = p;
+        double best = -1.0;
+#pragma unroll
+        for (int k = p / LPH; k < (7 + LPH - 1) / LPH; ++k) {
+            const int i = LPH * k + r;
+            const bool row_ok = i >= p && i < 7;
+#pragma unroll
+            for (int j = p; j < 9; ++j) {
+                const double v = fabs(SFM_SB2(row_ok ? i : p, j));
+                if (row_ok && v > best) { best = v; bi = i; bj = j; }
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < LPH; off <<= 1) {
+            const double ob = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
+            // (equal values in different rows: the earlier row comes first in the scan; a lane
+            // that found nothing still holds (-1, p, p), like its partner then)
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; bj = oj; }
+        }
+        if (!(best > 0.0)) ok = false;
+        // row swap p <-> bi, columns dealt out among the lanes
+#pragma unroll
+        for (int k = 0; k < (9 + LPH - 1) / LPH; ++k) {
+            const int j = LPH * k + r;
+            if (j < 9) {
+                const double a = SFM_SB2(p, j), b = SFM_SB2(bi, j);
+                SFM_SB2(bi, j) = a;
+                SFM_SB2(p, j) = b;
+            }
+        }
+        handover();
+        // column swap p <-> bj, rows dealt out
+#pragma unroll
+        for (int k = 0; k < (7 + LPH - 1) / LPH; ++k) {
+            const int i = LPH * k + r;
+            if (i < 7) {
+                const double a = SFM_SB2(i, p), b = SFM_SB2(i, bj);
+                SFM_SB2(i, bj) = a;
+                SFM_SB2(i, p) = b;
+            }
+        }
+        {
+            const unsigned long long np = (perm >> (4 * p)) & 15ull, nb = (perm >> (4 * bj)) & 15ull;
+            perm &= ~((15ull << (4 * p)) | (15ull << (4 * bj)));
+            perm |= (nb << (4 * p)) | (np << (4 * bj));
+        }
+        handover();
+        // the pivot row divided by the pivot, columns dealt out
+        const double piv = SFM_SB2(p, p);
+        handover();  // (everybody has the pivot before it is overwritten)
+#pragma unroll
+        for (int k = 0; k < (8 - p + LPH - 1) / LPH; ++k) {
+            const int j = p + 1 + LPH * k + r;
+            if (j < 9) SFM_SB2(p, j) = SFM_SB2(p, j) / piv;
+        }
+        if (r == 0) SFM_SB2(p, p) = 1.0;
+        handover();
+        double rowp[9];
+#pragma unroll
+        for (int j = p + 1; j < 9; ++j) rowp[j] = SFM_SB2(p, j);
+#pragma unroll
+        for (int k = 0; k < (7 + LPH - 1) / LPH; ++k) {
+            const int i = LPH * k + r;
+            if (i < 7 && i != p) {
+                const double f = SFM_SB2(i, p);
+#pragma unroll
+                for (int j = p + 1; j < 9; ++j) SFM_SB2(i, j) = SFM_SB2(i, j) - f * rowp[j];
+                SFM_SB2(i, p) = 0.0;
+            }
+        }
+        handover();
+    }
+    if (!ok) return false;
+    // The two null-space vectors through the permutation: entry `col` of vector k is
+    // -A[jj][7 + k] for jj < 7 and 1 / 0 for the two free columns, where perm[jj] = col.
+    // Lane r delivers the pencil's entries i = r, r + LPH, ...: f2[i] = N1[i], f1[i] = N0[i] - N1[i].
+#pragma unroll
+    for (int k = 0; k < (9 + LPH - 1) / LPH; ++k) {
+        const int i = LPH * k + r;
+        if (i < 9) {
+            double n0 = 0.0, n1 = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < 9; ++jj) {
+                const int col = (int)((perm >> (4 * jj)) & 15ull);
+                if (col == i) {
+                    n0 = jj < 7 ? -SFM_SB2(jj < 7 ? jj : 0, 7) : (jj == 7 ? 1.0 : 0.0);
+                    n1 = jj < 7 ? -SFM_SB2(jj < 7 ? jj : 0, 8) : (jj == 8 ? 1.0 : 0.0);
+                }
+            }
+            if (writes) {
+                dst[i] = n0 - n1;
+                dst[9 + i] = n1;
+            }
+        }
+    }
+#undef SFM_SB2
+    return true;
+}
+
+template <int LPH>
+__global__ void __launch_bounds__(64) ransac_solve7_split_kernel(const RansacProb* __restrict__ probs, int hyp0,
+                                                                 int n_hyp, int gen_rows)
+{
+    constexpr int HPW = 64 / LPH;
+    __shared__ double sA[63 * HPW];
+    const RansacProb pb = probs[blockIdx.y];
+    const int lane = threadIdx.x;
+    const int h = lane / LPH, r = lane % LPH;
+    const int hyp = hyp0 + blockIdx.x * HPW + h;
+    const bool in_range = hyp < hyp0 + n_hyp;
+    const int n = *pb.n_ptr;
+    const int valid = gen_rows > 0 ? (n == 7 ? 1 : gen_rows) : pb.result[R_VALID];
+    bool active = in_range && n >= 7 && hyp < valid;
+    int idx[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) idx[k] = 0;
+    float m1[14], m2[14];
+    auto gather = [&]() {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const float2 u = ((const float2*)pb.f1)[idx[k]];
+            const float2 v = ((const float2*)pb.f2)[idx[k]];
+            m1[2 * k] = u.x; m1[2 * k + 1] = u.y;
+            m2[2 * k] = v.x; m2[2 * k + 1] = v.y;
+        }
+    };
+    // (the lanes of a hypothesis draw the same rows; each checks one of the two images for collinear points)
+    if (gen_rows > 0) {
+        if (n >= 7 && blockIdx.x == 0 && lane == 0) {
+            pb.result[R_VALID] = valid;
+            if (n == 7) pb.result[R_DIRECT] = 1;
+        }
+        if (active) {
+            if (n == 7) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) idx[k] = k;
+                gather();
+            } else {
+                bool ok = false;
+                for (unsigned u = 0; u < 64 && !ok; ++u) {
+                    for (int i = 0; i < 7; ++i) {
+                        for (unsigned t = 0;; ++t) {
+                            const int v = fixed_draw(n, (unsigned)hyp, u, (unsigned)i, t);
+                            int j = 0;
+                            for (; j < i; ++j)
+                                if (idx[j] == v) break;
+                            if (j == i) { idx[i] = v; break; }
+                        }
+                    }
+                    gather();
+                    float mm[14];
+#pragma unroll
+                    for (int k = 0; k < 14; ++k) mm[k] = (r & 1) ? m2[k] : m1[k];
+                    bool bad = have_collinear(mm, 7);
+                    bad = bad || __shfl_xor((int)bad, 1) != 0;
+                    ok = !bad;
+                }
+                if (!ok) idx[0] = -1;
+            }
+            if (r == 0) {
+                int* row = pb.table + (size_t)hyp * 7;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) row[k] = idx[k];
+            }
+        }
+    } else if (active) {
+        const int* row = pb.table + (size_t)hyp * 7;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) idx[k] = row[k];
+    }
+    if (active && idx[0] < 0) active = false;  // the row could not be drawn
+    if (!active) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) idx[k] = 0;
+    }
+    if (n > 0) {
+        if (!(gen_rows > 0 && active)) gather();
+    } else {
+#pragma unroll
+        for (int k = 0; k < 14; ++k) m1[k] = m2[k] = 0.f;
+    }
+    double* dst = pb.models + (size_t)(in_range ? hyp : hyp0) * 90;
+    const bool ok = seven_point_pencil_split<LPH>(sA, h, r, m1, m2, dst, in_range && active);
+    if (!in_range || r != 0) return;
+    pb.nmodels[hyp] = (active && ok) ? -1 : 0;
+}
+
 // Three lanes per hypothesis (21 hypotheses per wavefront, lane 63 idle), one
 // interval of the cubic each: the Newton loops of the three intervals run side
 // by side instead of one after the other, and three times as many wavefronts
@@ -2505,12 +2736,28 @@ hipError_t launch_ransac_table_fixed(hipStream_t s, const RansacProb* probs, int
     return hipGetLastError();
 }
 hipError_t launch_ransac_solve(hipStream_t s, const RansacProb* probs, int n_prob, int model, int hyp0, int n_hyp,
-                               int gen_rows)
+                               int gen_rows, int split_mode)
 {
     if (model == SFM_GPU_MODEL_FUNDAMENTAL)
     {
-        hipLaunchKernelGGL(ransac_solve7_kernel, dim3((n_hyp + 63) / 64, n_prob), dim3(64), 0, s, probs, hyp0, n_hyp,
-                           gen_rows);
+        // One lane per hypothesis needs 32 KB of LDS per wavefront, five wavefronts per
+        // CU: a batch with more wavefronts than that at once runs in rounds, and beside
+        // the descriptor conversion of the next batch (bench.py) it takes 100 us where
+        // two lanes per hypothesis take 87 (alone 52 against 61: the split pays in
+        // hand-overs).  Small batches stay with one lane (23 against 38 us per wavefront).
+#ifndef SFM_SOLVE7_LPH
+#define SFM_SOLVE7_LPH 2
+#endif
+        const bool split = SFM_SOLVE7_LPH > 1 &&
+                           (split_mode < 0 ? (size_t)((n_hyp + 63) / 64) * (size_t)n_prob >= 1280 : split_mode > 0);
+        if (!split) {
+            hipLaunchKernelGGL(ransac_solve7_kernel, dim3((n_hyp + 63) / 64, n_prob), dim3(64), 0, s, probs, hyp0,
+                               n_hyp, gen_rows);
+        } else {
+            constexpr int LPH = SFM_SOLVE7_LPH > 1 ? SFM_SOLVE7_LPH : 2, HPW = 64 / LPH;
+            hipLaunchKernelGGL((ransac_solve7_split_kernel<LPH>), dim3((n_hyp + HPW - 1) / HPW, n_prob), dim3(64), 0,
+                               s, probs, hyp0, n_hyp, gen_rows);
+        }
         const int per_wg = ROOTS7_WAVES * 21;
         hipLaunchKernelGGL(ransac_roots7_kernel, dim3((n_hyp + per_wg - 1) / per_wg, n_prob), dim3(ROOTS7_WAVES * 64),
                            0, s, probs, hyp0, n_hyp);

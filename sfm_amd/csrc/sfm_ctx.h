@@ -129,6 +129,7 @@ struct sfm_gpu_ctx {
     int knn_variant = -1;  // -1: planner decides
     int score_filter = 1;  // test hooks of the RANSAC scoring pass (sfm_gpu_debug.h)
     int score_prune = 1;
+    int solver_split = -1;  // seven-point elimination: -1 by batch size, 0 one lane per hypothesis, 1 two
     // this device's copy of the library's static working memory (the calls that
     // must not allocate work there); resolved once per device at creation
     void* static_scratch = nullptr;

@@ -113,8 +113,16 @@ def test_essential_degenerate_sizes(gpu_ctx, oracle):
     assert r["ok"] == o["ok"] and (mask == o["mask"]).all()
 
 
-@pytest.mark.parametrize("seed,n", [(21, 3300), (22, 900)])
-def test_fundamental_fixed_and_adaptive(gpu_ctx, oracle, full_counts, seed, n):
+@pytest.fixture(params=[0, 1], ids=["one_lane_per_hypothesis", "two_lanes_per_hypothesis"])
+def solver_split(request, gpu_ctx):
+    """Both forms of the seven-point elimination, whatever the batch size would pick."""
+    gpu_ctx.check(gpu_ctx._L.sfm_gpu_debug_set_solver_split(gpu_ctx.handle, request.param))
+    yield request.param
+    gpu_ctx.check(gpu_ctx._L.sfm_gpu_debug_set_solver_split(gpu_ctx.handle, -1))
+
+
+@pytest.mark.parametrize("seed,n", [(21, 3300), (22, 900), (23, 40)])
+def test_fundamental_fixed_and_adaptive(gpu_ctx, oracle, full_counts, solver_split, seed, n):
     p1, p2, _, _ = synth.two_view(n, seed, inlier_frac=0.8)
     nh = 512
     F, mask, r = matcher.findFundamentalMat(gpu_ctx, p1, p2, ransacReprojThreshold=3.0,
