@@ -1441,7 +1441,7 @@ KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant
 }
 
 hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_rows_alloc_max,
-                       const KnnPlan& plan)
+                       const KnnPlan& plan, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     const int qblocks = (q_rows_alloc_max + plan.q_per_block - 1) / plan.q_per_block;
     const int splits = plan.n_splits;
@@ -1457,11 +1457,11 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
 #endif
     const dim3 grid((unsigned)total);
 #define SFM_KNN2(QB, WAVES, ABL)                                                                  \
-    hipLaunchKernelGGL((knn2_mfma_kernel<QB, WAVES, ABL>), grid, dim3(WAVES * 64), 0, s, jobs_dev, \
-                       plan.chunks_per_split, qblocks, splits, mode)
+    hipExtLaunchKernelGGL((knn2_mfma_kernel<QB, WAVES, ABL>), grid, dim3(WAVES * 64), 0, s, ev_start, ev_stop, 0, \
+                          jobs_dev, plan.chunks_per_split, qblocks, splits, mode)
 #define SFM_KNN16W(W, ABL)                                                                       \
-    hipLaunchKernelGGL((knn2_mfma16_kernel<W, ABL>), grid, dim3(W * 64), 0, s, jobs_dev, plan.chunks_per_split, \
-                       qblocks, splits, mode)
+    hipExtLaunchKernelGGL((knn2_mfma16_kernel<W, ABL>), grid, dim3(W * 64), 0, s, ev_start, ev_stop, 0, jobs_dev, \
+                          plan.chunks_per_split, qblocks, splits, mode)
 #define SFM_KNN16(ABL)              \
     do {                            \
         if (plan.variant == 5)      \

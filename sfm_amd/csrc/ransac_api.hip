@@ -568,8 +568,8 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
         SFM_HIP(ctx, hipMemcpyAsync(djobs, blob.data(), blob_b, hipMemcpyHostToDevice, s));
     }
     {
-        ProfScope ps(ctx, "knn2_mfma");
-        SFM_HIP(ctx, launch_knn2(s, djobs, g, pl.qalloc_max, plan));
+        ProfScope ps(ctx, "knn2_mfma", true);
+        SFM_HIP(ctx, launch_knn2(s, djobs, g, pl.qalloc_max, plan, ps.a, ps.b));
     }
     {
         ProfScope ps(ctx, "knn_finalize");

@@ -1899,9 +1899,13 @@ __device__ __forceinline__ int score_span(const RansacProb& pb, const ScoreLane<
                 parked[n_parked * 64 + lane] = (unsigned short)(idx - i0);
                 ++n_parked;
             } else {
-                double M[9];  // rare: the lane's queue is full
+                // rare: the lane's queue is full.  (The pointer is made opaque so that these loads
+                // stay here: hoisted out of the loop they would hold 18 registers through it.)
+                const double* mp = m.Mg;
+                asm volatile("" : "+v"(mp));
+                double M[9];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) M[k] = m.Mg[k];
+                for (int k = 0; k < 9; ++k) M[k] = mp[k];
                 cnt += exact(M, idx);
             }
         };

@@ -257,7 +257,10 @@ struct ProfScope {
     KernelTimer* t = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
     bool marked = false;
-    ProfScope(sfm_gpu_ctx* ctx, const char* name) : c(ctx)
+    // attach: the scope holds one launch that takes the two events itself
+    // (hipExtLaunchKernelGGL): nothing is recorded around it, the queue gets no barrier
+    bool attach = false;
+    ProfScope(sfm_gpu_ctx* ctx, const char* name, bool attach_ = false) : c(ctx), attach(attach_)
     {
         if (roctx_api().push) {
             roctx_api().push(name);
@@ -267,14 +270,14 @@ struct ProfScope {
         if (!c->profile_only.empty() && c->profile_only != name) return;
         t = &c->timers[name];
         t->name = name;
-        if (!c->take_event(&a) || !c->take_event(&b)) { t = nullptr; return; }
-        (void)hipEventRecord(a, c->stream);
+        if (!c->take_event(&a) || !c->take_event(&b)) { t = nullptr; a = b = nullptr; return; }
+        if (!attach) (void)hipEventRecord(a, c->stream);
     }
     ~ProfScope()
     {
         if (marked) roctx_api().pop();
         if (!t) return;
-        (void)hipEventRecord(b, c->stream);
+        if (!attach) (void)hipEventRecord(b, c->stream);
         t->pending.emplace_back(a, b);
     }
 };

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <string>
@@ -102,8 +103,10 @@ struct KnnPlan {
     int group_mode;  // geometry of the row groups in the sweep's records: 0 = 32x32 tiles, 1 = 16x16 tiles
 };
 KnnPlan plan_knn(int n_query_max, int n_train_max, int n_jobs, int force_variant);
+// ev_start / ev_stop (may be null): events attached to the launch itself -- they take the dispatch's own
+// start and end times, and unlike events recorded around it they put no barrier into the queue
 hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_rows_alloc_max,
-                       const KnnPlan& plan);
+                       const KnnPlan& plan, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // skip_ratio > 0 (k = 2 only): queries that fail the ratio test
 // d1 < skip_ratio * d2 end with counts = 0 (those that certainly fail it get no
 // exact neighbours at all); counts = 2 then means "passes".  launch_knn_redo
