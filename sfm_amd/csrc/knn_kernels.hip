@@ -74,96 +74,110 @@ __device__ __forceinline__ uint32_t pack4_checked(float4 f, ValueCheck& chk)
     return (lo | hi) ^ 0x80808080u;
 }
 
-template <int DTYPE>
+template <int DTYPE, int RPL>
 __global__ void __launch_bounds__(256) prep_rows_kernel(const PrepJob* __restrict__ jobs, int32_t* err_flag)
 {
+    // RPL rows per lane (rows 32 apart), all their loads issued before anything else.  Measured
+    // with 1 / 2 / 4: 107 / 114.5 / 122.5 us alone, 0.805 / 0.842 / 0.830 ms per bench step: one row
+    // per lane it is, with the loads ahead of the row's bounds branch (112 us and 0.796 ms before).
     constexpr int TS = 36;  // dwords per transposition row (16-B aligned, spreads banks)
     __shared__ __attribute__((aligned(16))) uint32_t tr[32 * TS];
     const PrepJob job = jobs[blockIdx.y];
     const ImageDev img = job.img;
-    if ((int)blockIdx.x * 32 >= img.rows_alloc) return;
+    if ((int)blockIdx.x * 32 * RPL >= img.rows_alloc) return;
     const unsigned char* src = job.src;
     const size_t step = job.step;
     const int n = img.n;
-    const int rl = threadIdx.x >> 3;  // row within the workgroup
+    const int rl = threadIdx.x >> 3;  // row within the workgroup's block of 32
     const int seg = threadIdx.x & 7;
-    const int row = blockIdx.x * 32 + rl;
     const bool wide = (((uintptr_t)src | step) & 15) == 0;  // 16-B loads allowed
-    uint32_t P[4] = {0u, 0u, 0u, 0u};  // value 128 -> byte 0
-    bool bad = false;
-    ValueCheck chk;
-    if (row < n) {
-        const unsigned char* rp = src + (size_t)row * step;
-        if (DTYPE == SFM_GPU_DESC_F32) {
-            // piece j of the lane: values 32j + 4seg .. +3
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v early[RPL][4] = {};
+    if (DTYPE == SFM_GPU_DESC_F32 && wide && n > 0) {  // (rows past the end read row 0 and are ignored)
+        // read once, never again: streaming loads leave the caches to the kernels this one runs
+        // beside (123 -> 114.5 us alone, 0.8175 -> 0.8135 ms per bench step)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float* fp = (const float*)rp + j * 32 + seg * 4;
-                float4 f;
-                if (wide) {
-                    // read once, never again: a streaming load leaves the caches to the kernels
-                    // this one runs beside (123 -> 114.5 us alone, 0.8175 -> 0.8135 ms per bench step)
-                    typedef float f4v __attribute__((ext_vector_type(4)));
-                    const f4v t = __builtin_nontemporal_load((const f4v*)fp);
-                    f = make_float4(t.x, t.y, t.z, t.w);
-                }
-                else f = make_float4(fp[0], fp[1], fp[2], fp[3]);
-                P[j] = pack4_checked(f, chk);
-            }
-            bad = chk.bad();
-        } else {
-            // the lane's 16 consecutive bytes
-            const unsigned char* bp = rp + seg * 16;
-            if (wide) {
-                const uint4 u = *(const uint4*)bp;
-                P[0] = u.x; P[1] = u.y; P[2] = u.z; P[3] = u.w;
-            } else {
+        for (int r = 0; r < RPL; ++r) {
+            const int row = blockIdx.x * 32 * RPL + 32 * r + rl;
+            const float* fp0 = (const float*)(src + (size_t)(row < n ? row : 0) * step) + seg * 4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    P[j] = (uint32_t)bp[4 * j] | ((uint32_t)bp[4 * j + 1] << 8) | ((uint32_t)bp[4 * j + 2] << 16) |
-                           ((uint32_t)bp[4 * j + 3] << 24);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) P[j] ^= 0x80808080u;
+            for (int j = 0; j < 4; ++j) early[r][j] = __builtin_nontemporal_load((const f4v*)(fp0 + j * 32));
         }
     }
-    if (bad) {
-        P[0] = P[1] = P[2] = P[3] = 0u;
-        atomicOr(err_flag, 1);
-    }
-    int n2 = 0, sm = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        n2 = __builtin_amdgcn_sdot4((int)P[j], (int)P[j], n2, false);
-        sm = __builtin_amdgcn_sdot4((int)P[j], 0x01010101, sm, false);
-    }
-#pragma unroll
-    for (int off = 4; off > 0; off >>= 1) {
-        n2 += __shfl_xor(n2, off);
-        sm += __shfl_xor(sm, off);
-    }
-    if (row >= img.rows_alloc) return;
-    uint4 o;
-    if (DTYPE == SFM_GPU_DESC_F32) {
-        // the 8 lanes of a row belong to one wave: exchange through LDS needs
-        // no workgroup barrier
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tr[rl * TS + j * 8 + seg] = P[j];
-        __builtin_amdgcn_wave_barrier();
-        o = *(const uint4*)&tr[rl * TS + seg * 4];
-    } else {
-        o = make_uint4(P[0], P[1], P[2], P[3]);
-    }
-    *(uint4*)(img.desc + (size_t)row * DIM + seg * 16) = o;
-    if (seg == 0) {
+    for (int r = 0; r < RPL; ++r) {
+        const int row = blockIdx.x * 32 * RPL + 32 * r + rl;
+        uint32_t P[4] = {0u, 0u, 0u, 0u};  // value 128 -> byte 0
+        bool bad = false;
+        ValueCheck chk;
         if (row < n) {
-            const int tn = n2 + 2 * sm;  // = sum (v-127)^2 - 128, in [-128, 2097024]
-            img.qn[row] = n2;
-            img.cin[row] = (tn >> 1) + KEY_OFFSET;  // arithmetic shift = floor
-            if (job.kp_src && img.kp) img.kp[row] = job.kp_src[row];
+            const unsigned char* rp = src + (size_t)row * step;
+            if (DTYPE == SFM_GPU_DESC_F32) {
+                // piece j of the lane: values 32j + 4seg .. +3
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* fp = (const float*)rp + j * 32 + seg * 4;
+                    float4 f;
+                    if (wide) f = make_float4(early[r][j].x, early[r][j].y, early[r][j].z, early[r][j].w);
+                    else f = make_float4(fp[0], fp[1], fp[2], fp[3]);
+                    P[j] = pack4_checked(f, chk);
+                }
+                bad = chk.bad();
+            } else {
+                // the lane's 16 consecutive bytes
+                const unsigned char* bp = rp + seg * 16;
+                if (wide) {
+                    const uint4 u = *(const uint4*)bp;
+                    P[0] = u.x; P[1] = u.y; P[2] = u.z; P[3] = u.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        P[j] = (uint32_t)bp[4 * j] | ((uint32_t)bp[4 * j + 1] << 8) | ((uint32_t)bp[4 * j + 2] << 16) |
+                               ((uint32_t)bp[4 * j + 3] << 24);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) P[j] ^= 0x80808080u;
+            }
+        }
+        if (bad) {
+            P[0] = P[1] = P[2] = P[3] = 0u;
+            atomicOr(err_flag, 1);
+        }
+        int n2 = 0, sm = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            n2 = __builtin_amdgcn_sdot4((int)P[j], (int)P[j], n2, false);
+            sm = __builtin_amdgcn_sdot4((int)P[j], 0x01010101, sm, false);
+        }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+            n2 += __shfl_xor(n2, off);
+            sm += __shfl_xor(sm, off);
+        }
+        if (row >= img.rows_alloc) continue;
+        uint4 o;
+        if (DTYPE == SFM_GPU_DESC_F32) {
+            // the 8 lanes of a row belong to one wave: exchange through LDS needs
+            // no workgroup barrier
+            if (r > 0) __builtin_amdgcn_wave_barrier();  // (the row before has been read out)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tr[rl * TS + j * 8 + seg] = P[j];
+            __builtin_amdgcn_wave_barrier();
+            o = *(const uint4*)&tr[rl * TS + seg * 4];
         } else {
-            img.qn[row] = 0;
-            img.cin[row] = PAD_CIN;
+            o = make_uint4(P[0], P[1], P[2], P[3]);
+        }
+        *(uint4*)(img.desc + (size_t)row * DIM + seg * 16) = o;
+        if (seg == 0) {
+            if (row < n) {
+                const int tn = n2 + 2 * sm;  // = sum (v-127)^2 - 128, in [-128, 2097024]
+                img.qn[row] = n2;
+                img.cin[row] = (tn >> 1) + KEY_OFFSET;  // arithmetic shift = floor
+                if (job.kp_src && img.kp) img.kp[row] = job.kp_src[row];
+            } else {
+                img.qn[row] = 0;
+                img.cin[row] = PAD_CIN;
+            }
         }
     }
 }
@@ -1389,11 +1403,16 @@ __global__ void __launch_bounds__(64) mfma16_layout_probe_kernel(const int8_t* A
 hipError_t launch_prep_rows(hipStream_t s, const PrepJob* jobs_dev, int n_jobs, int rows_alloc_max,
                             int dtype, int32_t* err_flag)
 {
-    const dim3 grid((rows_alloc_max + 31) / 32, n_jobs);
+#ifndef SFM_PREP_RPL
+#define SFM_PREP_RPL 1
+#endif
     if (dtype == SFM_GPU_DESC_F32)
-        hipLaunchKernelGGL(prep_rows_kernel<SFM_GPU_DESC_F32>, grid, dim3(256), 0, s, jobs_dev, err_flag);
+        hipLaunchKernelGGL((prep_rows_kernel<SFM_GPU_DESC_F32, SFM_PREP_RPL>),
+                           dim3((rows_alloc_max + 32 * SFM_PREP_RPL - 1) / (32 * SFM_PREP_RPL), n_jobs), dim3(256), 0, s,
+                           jobs_dev, err_flag);
     else
-        hipLaunchKernelGGL(prep_rows_kernel<SFM_GPU_DESC_U8>, grid, dim3(256), 0, s, jobs_dev, err_flag);
+        hipLaunchKernelGGL((prep_rows_kernel<SFM_GPU_DESC_U8, 1>), dim3((rows_alloc_max + 31) / 32, n_jobs), dim3(256),
+                           0, s, jobs_dev, err_flag);
     return hipGetLastError();
 }
 
