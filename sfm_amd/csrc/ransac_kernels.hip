@@ -2059,15 +2059,26 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
     const unsigned bz = (by_group || stage) ? blockIdx.x : blockIdx.z;
     const unsigned gdx = by_group ? gridDim.z : gridDim.x;
     const RansacProb pb = probs[bz];
-    const int nlist = min(__builtin_amdgcn_readfirstlane(pb.result[R_NLIST]), list_limit);
+    // The problem's whole result block in one scalar load (nothing this launch reads from it is
+    // written during the launch: a stage writes the live mark of the NEXT stage only), so that
+    // what the wavefront needs to know before its first model comes in one round trip, not one
+    // per early-exit test.
+    typedef const int __attribute__((address_space(4))) cint;
+    int res[R_COUNT];
+    {
+        cint* RES = (cint*)(uintptr_t)pb.result;
+#pragma unroll
+        for (int k = 0; k < R_COUNT; ++k) res[k] = RES[k];
+    }
+    const int n_all = *(cint*)(uintptr_t)pb.n_ptr;
+    const int nlist = min(res[R_NLIST], list_limit);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pts_begin = slot_begin >= 0 ? __builtin_amdgcn_readfirstlane(pb.result[slot_begin]) : 0;
-    const int n_all = __builtin_amdgcn_readfirstlane(*pb.n_ptr);
+    const int pts_begin = slot_begin >= 0 ? res[slot_begin] : 0;
     int n = n_all;
-    if (slot_end >= 0) n = min(n, __builtin_amdgcn_readfirstlane(pb.result[slot_end]));
+    if (slot_end >= 0) n = min(n, res[slot_end]);
     int chunk_pts;
     if (stage) {
-        const int live = __builtin_amdgcn_readfirstlane(pb.result[live_slot]);
+        const int live = res[live_slot];
         const int len = n - pts_begin;
         if (live <= 0 || len <= 0) return;
         // (the grid has at least as many items as the list has groups, hence >= live)
@@ -2089,16 +2100,16 @@ __global__ void __launch_bounds__(SCORE_WAVES * 64) ransac_score_kernel(const Ra
     const int lane = threadIdx.x & 63;
     __shared__ unsigned short parked_all[SCORE_WAVES * SCORE_QCAP * 64];
     unsigned short* parked = parked_all + wv * (SCORE_QCAP * 64);
-    const float R = __int_as_float(__builtin_amdgcn_readfirstlane(pb.result[R_MAXABS]));
+    const float R = __int_as_float(res[R_MAXABS]);
     if (!(R < 1e18f)) use_filter = 0;  // coordinates that are huge, infinite or not numbers: double precision only
     for (int g0 = (stage ? bx : bx * SCORE_WAVES + wv) * 64; g0 < nlist; g0 += gdx * SCORE_WAVES * 64) {
         const bool active = g0 + lane < nlist;
         // the stages read the ordered list where ransac_sortplan_kernel left it
-        const int32_t* lst = stage ? pb.list2 + __builtin_amdgcn_readfirstlane(pb.result[R_TOP]) : pb.list;
+        const int32_t* lst = stage ? pb.list2 + res[R_TOP] : pb.list;
         const int e = lst[active ? g0 + lane : g0];
         if (stage) {
             // (every piece of the group sees the same counts: the stage before is complete)
-            const int bound = __builtin_amdgcn_readfirstlane(pb.result[R_BOUND]);
+            const int bound = res[R_BOUND];
             const bool alive = active && pb.counts[e] + (n_all - pts_begin) >= bound;
             if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
             if (by == 0 && lane == 0) atomicMax(&pb.result[live_slot + 1], g0 / 64 + 1);
