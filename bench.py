@@ -501,7 +501,7 @@ def main():
         step(it)
     ctx.synchronize()
     kern = {}
-    for name in ("prep_rows", "knn2_mfma", "knn_finalize", "ratio_compact", "ransac_prep",
+    for name in ("prep_rows", "knn2_mfma", "knn_finalize", "knn_redo", "ratio_compact", "ransac_prep",
                  "ransac_table", "ransac_solve", "ransac_score", "ransac_select", "ransac_mask",
                  "inlier_compact"):
         ms, cnt = (pctx if name == "prep_rows" else ctx).profile_query(name)

@@ -28,7 +28,8 @@ def main():
             t = ms / k * 1e-3
             rc = np.zeros(1, np.int32)
             ctx._L.sfm_gpu_debug_redo_count(ctx.handle, rc.ctypes.data)
-            print("   queries through the exhaustive pass: %d" % rc[0])
+            msr, kr = ctx.profile_query("knn_redo")
+            print("   redo queries: %d  redo kernel %.1f us" % (rc[0], msr / max(kr, 1) * 1e3))
             print("n=%d variant=%d knn2_mfma %.1f us  %.1f TOP/s (%.1f%% of 5000)  finalize %.1f us" %
                   (n, variant, t * 1e6, ops / t / 1e12, ops / t / 5e15 * 100, msf / k * 1e3), flush=True)
         iq.close(); it.close()

@@ -43,7 +43,7 @@ def main():
     dt = (time.perf_counter() - t0) / reps
     print("%s %s: %d pairs of %d: %.3f ms/batch  %.0f pairs/s  good %.0f inliers %.1f" %
           (model, mode, B, n, dt * 1e3, B / dt, ng.mean(), ni.mean()))
-    for name in ("knn2_mfma", "knn_finalize", "ratio_compact", "ransac_prep", "ransac_table",
+    for name in ("knn2_mfma", "knn_finalize", "knn_redo", "ratio_compact", "ransac_prep", "ransac_table",
                  "ransac_solve", "ransac_score", "ransac_select", "ransac_mask", "inlier_compact"):
         ms, cnt = ctx.profile_query(name)
         if cnt:

@@ -836,93 +836,6 @@ __device__ __forceinline__ void merge3(u64& a1, u64& a2, u64& a3, u64 b1, u64 b2
     a3 = r3;
 }
 
-__device__ __forceinline__ void merge2(u64& a1, u64& a2, u64 b1, u64 b2)
-{
-    const bool afirst = a1 < b1;
-    const u64 nf = afirst ? a1 : b1;
-    const u64 ns = afirst ? (b1 < a2 ? b1 : a2) : (a1 < b2 ? a1 : b2);
-    a1 = nf;
-    a2 = ns;
-}
-
-// Float-ranked exhaustive pass for one query: ranks ALL train rows by
-// (sqrtf(d2) as float, row), exactly the reference ordering, at any d2, and writes
-// the query's k neighbours (and, with ratio > 0, the ratio verdict into its
-// count).  The whole workgroup (256 threads) works on the query: 8 lanes share a
-// row so that each load instruction fetches whole 128-B rows, every wavefront
-// takes 8 rows of each 32 and four such groups are in flight per step.  Called by
-// all threads of the workgroup; sh: 8 words of LDS.
-__device__ __forceinline__ void exhaustive_neighbours(const KnnJob& job, int q, int k, double ratio, u64* sh)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int sg = lane & 7, rsub = lane >> 3;
-    const u64 NONE = ~0ull;
-    const int r1 = job.n_train;
-    const v4i qv = *(const v4i*)(job.q_desc + (size_t)q * DIM + sg * 16);
-    const int qn = job.q_qn[q];
-    u64 f = NONE, s = NONE;
-    int d2f = 0x7FFFFFFF, lim = 0x7FFFFFFF;  // d2 of this lane's best / second best so far
-    constexpr int NG = 4;  // groups of 32 rows in flight
-    for (int base = wave * 8; base < r1; base += NG * 4 * 8) {
-        v4i tv[NG];
-        int tn[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int row = base + g * 32 + rsub;
-            const int rr = row < r1 ? row : 0;
-            tv[g] = *(const v4i*)(job.t_desc + (size_t)rr * DIM + sg * 16);
-            tn[g] = job.t_qn[rr];
-        }
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int row = base + g * 32 + rsub;
-            const bool ok = row < r1;
-            int acc = __builtin_amdgcn_sdot4(qv[0], tv[g][0], 0, false);
-            acc = __builtin_amdgcn_sdot4(qv[1], tv[g][1], acc, false);
-            acc = __builtin_amdgcn_sdot4(qv[2], tv[g][2], acc, false);
-            acc = __builtin_amdgcn_sdot4(qv[3], tv[g][3], acc, false);
-            acc += __shfl_xor(acc, 1);
-            acc += __shfl_xor(acc, 2);
-            acc += __shfl_xor(acc, 4);
-            const int d2 = qn + tn[g] - 2 * acc;
-            // rows come in ascending order, so a later row needs a float distance
-            // strictly below the second best's, hence a smaller d2
-            if (ok && sg == 0 && d2 < lim) {
-                const u64 key = ((u64)__float_as_uint(sqrt_d2((uint32_t)d2)) << 32) | (uint32_t)row;
-                if (key < f) { s = f; f = key; lim = d2f; d2f = d2; }
-                else if (key < s) { s = key; lim = d2; }
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) merge2(f, s, __shfl_xor(f, off), __shfl_xor(s, off));
-    if (lane == 0) {
-        sh[2 * wave] = f;
-        sh[2 * wave + 1] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u64 a1 = NONE, a2 = NONE;
-        for (int w = 0; w < 4; ++w) merge2(a1, a2, sh[2 * w], sh[2 * w + 1]);
-        const u64 e[2] = {a1, a2};
-        for (int j = 0; j < k; ++j) {
-            if (e[j] != NONE) {
-                sfm_gpu_dmatch m;
-                m.queryIdx = q;
-                m.imgIdx = 0;
-                m.trainIdx = (int32_t)(uint32_t)e[j];
-                m.distance = __uint_as_float((uint32_t)(e[j] >> 32));
-                job.out[(size_t)q * k + j] = m;
-            }
-        }
-        // ratio verdict in the count, as the rescan leaves it for the other queries
-        if (ratio > 0.0 && k == 2 && a2 != NONE &&
-            !((double)__uint_as_float((uint32_t)(a1 >> 32)) < ratio * (double)__uint_as_float((uint32_t)(a2 >> 32))))
-            job.counts[q] = 0;
-    }
-    __syncthreads();
-}
-
 // Exact neighbours from the sweep records.  32 lanes per query:
 //  1. the query's records (one per part and sweep lane) are reduced to the two best groups
 //     by (minimum x, tile, half) and to the smallest x of all the other groups;
@@ -940,7 +853,7 @@ __device__ __forceinline__ void exhaustive_neighbours(const KnnJob& job, int q, 
 //           group rows = 64*block + 16j + 4*quarter + i   (j, i = 0..3)
 constexpr int RESCAN_QPW = 32;  // queries per workgroup
 template <int GM>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7)))
+__global__ void __launch_bounds__(256)
 knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblocks, int map_mode, double ratio)
 {
     const double skip_r2 = ratio * ratio;  // 0 when the caller wants every neighbour
@@ -1030,14 +943,7 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
     }
     __shared__ int s_list2[RESCAN_QPW];
     __shared__ int s_n2;
-    __shared__ int s_redo[RESCAN_QPW];
-    __shared__ int s_nredo;
-    __shared__ u64 s_sh[8];
-    if (threadIdx.x == 0) {
-        s_n2 = 0;
-        s_nredo = 0;
-    }
-
+    if (threadIdx.x == 0) s_n2 = 0;
     __syncthreads();
     const int s_count = s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
     int n_need = s_count;
@@ -1289,8 +1195,8 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
                 }
             }
             if (redo) {
-                atomicAdd(job.redo, 1);  // (a count for the test hooks)
-                s_redo[atomicAdd(&s_nredo, 1)] = q;
+                const int slot = atomicAdd(job.redo, 1);
+                job.redo[1 + slot] = q;
             } else if (skip_r2 > 0.0 && !settled) {
                 // both records are final: the ratio verdict itself (main.cpp:192, in
                 // double on the float distances) goes into the count, 0 = fails, so
@@ -1301,14 +1207,137 @@ knn_rescan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int qblo
         job.counts[q] = cnt;
     }
     }  // listed queries
-    // Step 3, rare: the queries this workgroup could not settle from the two groups (a tie
-    // between group minima that matters, distances at 2^22 and beyond) go through the
-    // exhaustive float-ranked pass right here, the whole workgroup on one query at a time.
-    // (As a pair of launches of their own behind this kernel they cost a batch 16 us whether
-    // or not any query needed them.)
-    __syncthreads();
-    const int n_redo = s_nredo;
-    for (int it = 0; it < n_redo; ++it) exhaustive_neighbours(job, s_redo[it], k, ratio, s_sh);
+}
+
+// Float-ranked exhaustive pass for the queries flagged above: ranks train rows
+// by (sqrtf(d2) as float, row), exactly the reference ordering, at any d2.
+// Each flagged query is cut into segments of train rows handled by different
+// workgroups (knn_redo_scan_kernel, partial results parked in the sweep's
+// record buffer, which is free by now) and merged by knn_redo_merge_kernel.
+// 8 lanes share a row so that each load instruction fetches whole 128-B rows.
+constexpr int REDO_MAX_SEG = 64;
+
+__device__ __forceinline__ int redo_segments(const KnnJob& job, int n_redo, int n_splits, int max_seg)
+{
+    const long long cap = (long long)job.q_rows_alloc * n_splits;  // uint4 slots in job.partial
+    long long nseg = n_redo > 0 ? cap / n_redo : 1;
+    if (nseg > max_seg) nseg = max_seg;
+    return nseg < 1 ? 1 : (int)nseg;
+}
+
+__device__ __forceinline__ void merge2(u64& a1, u64& a2, u64 b1, u64 b2)
+{
+    const bool afirst = a1 < b1;
+    const u64 nf = afirst ? a1 : b1;
+    const u64 ns = afirst ? (b1 < a2 ? b1 : a2) : (a1 < b2 ? a1 : b2);
+    a1 = nf;
+    a2 = ns;
+}
+
+__global__ void __launch_bounds__(256)
+knn_redo_scan_kernel(const KnnJob* __restrict__ jobs, int n_splits, int max_seg)
+{
+    __shared__ u64 sh[2 * 4];
+    const KnnJob job = jobs[blockIdx.y];
+    const int n_redo = job.redo[0];
+    if (n_redo == 0) return;
+    const int nseg = redo_segments(job, n_redo, n_splits, max_seg);
+    const int seg_rows = ((job.n_train + nseg - 1) / nseg + 31) & ~31;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sg = lane & 7, rsub = lane >> 3;
+    const u64 NONE = ~0ull;
+    for (int u = blockIdx.x; u < n_redo * nseg; u += gridDim.x) {
+        const int item = u / nseg, seg = u - item * nseg;
+        const int q = job.redo[1 + item];
+        const int r0 = seg * seg_rows;
+        const int r1 = min(r0 + seg_rows, job.n_train);
+        const v4i qv = *(const v4i*)(job.q_desc + (size_t)q * DIM + sg * 16);
+        const int qn = job.q_qn[q];
+        u64 f = NONE, s = NONE;
+        int d2f = 0x7FFFFFFF, lim = 0x7FFFFFFF;  // d2 of this lane's best / second best so far
+        // four row groups per step, their loads issued together
+        for (int base = r0 + wave * 8; base < r1; base += 4 * 4 * 8) {
+            v4i tv[4];
+            int tn[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = base + g * 32 + rsub;
+                const int rr = row < r1 ? row : 0;
+                tv[g] = *(const v4i*)(job.t_desc + (size_t)rr * DIM + sg * 16);
+                tn[g] = job.t_qn[rr];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = base + g * 32 + rsub;
+                const bool ok = row < r1;
+                int acc = __builtin_amdgcn_sdot4(qv[0], tv[g][0], 0, false);
+                acc = __builtin_amdgcn_sdot4(qv[1], tv[g][1], acc, false);
+                acc = __builtin_amdgcn_sdot4(qv[2], tv[g][2], acc, false);
+                acc = __builtin_amdgcn_sdot4(qv[3], tv[g][3], acc, false);
+                acc += __shfl_xor(acc, 1);
+                acc += __shfl_xor(acc, 2);
+                acc += __shfl_xor(acc, 4);
+                const int d2 = qn + tn[g] - 2 * acc;
+                // rows come in ascending order, so a later row needs a float distance
+                // strictly below the second best's, hence a smaller d2
+                if (ok && sg == 0 && d2 < lim) {
+                    const u64 key = ((u64)__float_as_uint(sqrt_d2((uint32_t)d2)) << 32) | (uint32_t)row;
+                    if (key < f) { s = f; f = key; lim = d2f; d2f = d2; }
+                    else if (key < s) { s = key; lim = d2; }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) merge2(f, s, __shfl_xor(f, off), __shfl_xor(s, off));
+        if (lane == 0) {
+            sh[2 * wave] = f;
+            sh[2 * wave + 1] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 a1 = NONE, a2 = NONE;
+            for (int w = 0; w < 4; ++w) merge2(a1, a2, sh[2 * w], sh[2 * w + 1]);
+            uint4 o;
+            o.x = (uint32_t)a1;
+            o.y = (uint32_t)(a1 >> 32);
+            o.z = (uint32_t)a2;
+            o.w = (uint32_t)(a2 >> 32);
+            job.partial[u] = o;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+knn_redo_merge_kernel(const KnnJob* __restrict__ jobs, int n_splits, int k, int max_seg, double ratio)
+{
+    const KnnJob job = jobs[blockIdx.y];
+    const int n_redo = job.redo[0];
+    const int nseg = redo_segments(job, n_redo, n_splits, max_seg);
+    const u64 NONE = ~0ull;
+    for (int item = blockIdx.x * 256 + threadIdx.x; item < n_redo; item += gridDim.x * 256) {
+        const int q = job.redo[1 + item];
+        u64 a1 = NONE, a2 = NONE;
+        for (int seg = 0; seg < nseg; ++seg) {
+            const uint4 o = job.partial[(size_t)item * nseg + seg];
+            merge2(a1, a2, ((u64)o.y << 32) | o.x, ((u64)o.w << 32) | o.z);
+        }
+        const u64 e[2] = {a1, a2};
+        for (int j = 0; j < k; ++j) {
+            if (e[j] != NONE) {
+                sfm_gpu_dmatch m;
+                m.queryIdx = q;
+                m.imgIdx = 0;
+                m.trainIdx = (int32_t)(uint32_t)e[j];
+                m.distance = __uint_as_float((uint32_t)(e[j] >> 32));
+                job.out[(size_t)q * k + j] = m;
+            }
+        }
+        // ratio verdict in the count, as the rescan kernel leaves it
+        if (ratio > 0.0 && k == 2 && a2 != NONE &&
+            !((double)__uint_as_float((uint32_t)(a1 >> 32)) < ratio * (double)__uint_as_float((uint32_t)(a2 >> 32))))
+            job.counts[q] = 0;
+    }
 }
 
 // C = A(32x32 i8) * B(32x32 i8) through one v_mfma_i32_32x32x32_i8, operands
@@ -1522,6 +1551,19 @@ hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs
     else
         hipLaunchKernelGGL(knn_rescan_kernel<0>, dim3((unsigned)total), dim3(256), 0, s, jobs_dev, n_splits, k,
                            qblocks, mode, ratio);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_splits, int k, double skip_ratio)
+{
+    // flagged queries are rare: about 2048 workgroups in all are plenty, and a
+    // larger grid only costs launch time
+    const int gx = std::min(512, std::max(8, 2048 / (n_jobs > 0 ? n_jobs : 1)));
+    // with many jobs in flight a flagged query is cut into fewer, longer segments
+    const int max_seg = std::min(REDO_MAX_SEG, std::max(1, 512 / (n_jobs > 0 ? n_jobs : 1)));
+    hipLaunchKernelGGL(knn_redo_scan_kernel, dim3(gx, n_jobs), dim3(256), 0, s, jobs_dev, n_splits, max_seg);
+    hipLaunchKernelGGL(knn_redo_merge_kernel, dim3(4, n_jobs), dim3(256), 0, s, jobs_dev, n_splits, k, max_seg,
+                       skip_ratio > 0.0 && k == 2 ? skip_ratio : 0.0);
     return hipGetLastError();
 }
 

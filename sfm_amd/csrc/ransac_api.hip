@@ -583,6 +583,10 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
         ctx->front_recorded = true;
     }
     {
+        ProfScope ps(ctx, "knn_redo");
+        SFM_HIP(ctx, launch_knn_redo(s, djobs, g, plan.n_splits, 2, params->ratio));
+    }
+    {
         ProfScope ps(ctx, "ratio_compact");
         SFM_HIP(ctx, launch_ratio_compact(s, dpds, g, pl.nq_max, params->ratio));
     }

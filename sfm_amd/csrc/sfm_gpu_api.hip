@@ -152,6 +152,10 @@ int enqueue_knn(sfm_gpu_ctx* ctx, const ImageDev& q, const KnnWorkspace& ws, con
         ProfScope ps(timers ? ctx : nullptr, "knn_finalize");
         SFM_HIP(ctx, launch_knn_finalize(ctx->stream, ws.job, 1, q.n, plan.n_splits, k, plan.group_mode, 0.0));
     }
+    {
+        ProfScope ps(timers ? ctx : nullptr, "knn_redo");
+        SFM_HIP(ctx, launch_knn_redo(ctx->stream, ws.job, 1, plan.n_splits, k, 0.0));
+    }
     return SFM_GPU_OK;
 }
 

@@ -109,11 +109,12 @@ hipError_t launch_knn2(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int q_
                        const KnnPlan& plan, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // skip_ratio > 0 (k = 2 only): queries that fail the ratio test
 // d1 < skip_ratio * d2 end with counts = 0 (those that certainly fail it get no
-// exact neighbours at all); counts = 2 then means "passes".  The kernel also runs the
-// exhaustive float-ranked pass for the rare queries the records cannot settle; each job's
-// redo[0] must be zero at launch and counts them.
+// exact neighbours at all); counts = 2 then means "passes".  launch_knn_redo
+// must be given the same value.
 hipError_t launch_knn_finalize(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_query_max,
                                int n_splits, int k, int group_mode, double skip_ratio);
+hipError_t launch_knn_redo(hipStream_t s, const KnnJob* jobs_dev, int n_jobs, int n_splits, int k,
+                           double skip_ratio);
 // timing build only: the in-kernel stamps of the last 16x16 sweep, 8 words per workgroup
 hipError_t read_sweep_stamps(unsigned long long* out, int n_wg);
 // overwrites the LDS of every CU with a pattern (test hook)
