@@ -509,6 +509,7 @@ def main():
             kern[name] = {"avg_us": round(ms / cnt * 1e3, 2), "launches": cnt}
     if pctx is not ctx:
         pctx.profile_enable(False)
+    ctx.profile_enable(False)   # (the blocks below that want per-launch events switch them on themselves)
     # For reference, outside the timed region: the same steps alternating over
     # two unordered streams.  More pairs/s, but the sweep then shares the chip with
     # the other step's kernels and its own duration grows: not the headline.
