@@ -35,6 +35,8 @@ dealt pair list, all-reduce of the count matrices); `cpu_baseline` is the CPU
 oracle timed on this host's cores on full pairs of the same workload.
 """
 import argparse
+import contextlib
+import gc
 import hashlib
 import json
 import os
@@ -50,6 +52,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 INT8_DENSE_PEAK_TOPS = 5000.0  # MI355X dense int8 MFMA: 2x the bf16 rate (~2.5 PF)
+
+
+@contextlib.contextmanager
+def no_gc_pause():
+    """A timed region without the interpreter's cycle collector: a full collection of this process takes
+    30-40 ms (seen as one such _end call among fifty of 0.7 ms), which is none of the measured work."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def make_pairs(n_pairs, n_desc, seed0, wrong_frac=0.0):
@@ -458,12 +474,13 @@ def main():
         lane.ctx.profile_select("knn2_mfma")
         lane.ctx.profile_enable(True)
         lane.ctx.profile_reset()
-    fence()
-    stage[0] = "timed region"
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
+    with no_gc_pause():
+        fence()
+        stage[0] = "timed region"
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        fence()
+        elapsed = time.perf_counter() - t0
     stage[0] = "after the timed region"
     per_set = {i: (float(np.mean(v[0])), float(np.mean(v[1]))) for i, v in sorted(last.items())}
     n_good = np.concatenate([last[i][0] for i in sorted(last)])
@@ -525,10 +542,11 @@ def main():
         ctx.profile_reset()
         two[1].ctx.profile_reset()
         k2 = max(10, min(args.steps, 40))
-        t1 = time.perf_counter()
-        run_steps(k2, two)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
+        with no_gc_pause():
+            t1 = time.perf_counter()
+            run_steps(k2, two)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
         ms_a, cnt_a = ctx.profile_query("knn2_mfma")
         ms_b, cnt_b = two[1].ctx.profile_query("knn2_mfma")
         ctx.profile_enable(False)
@@ -539,19 +557,20 @@ def main():
                          "kernels of different steps overlap, so per-kernel durations are not the kernels' own"}
 
     # The same loop with each batch's records also copied to pinned host memory
-    # behind the batch (a kernel on a side stream writes exactly the records that
-    # exist): what a host that consumes selectMatches on the CPU, as the
-    # reference's later stages do, would see.
+    # behind the batch (on a side stream, beside the next batch's sweep): what a
+    # host that consumes selectMatches on the CPU, as the reference's later stages
+    # do, would see.
     to_host = None
     if args.records and args.streams == 1:
         stage[0] = "records to host"
         run_steps(4, to_host=True)
         torch.cuda.synchronize()
         k3 = max(10, min(args.steps, 50))
-        t1 = time.perf_counter()
-        run_steps(k3, to_host=True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
+        with no_gc_pause():
+            t1 = time.perf_counter()
+            run_steps(k3, to_host=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
         ok = True
         for i, (g, c, o, k) in last.items():
             if k <= lanes[0].k - 2:
@@ -564,7 +583,7 @@ def main():
                    "record_bytes_per_step": int(16 * sum(int(v[1].sum()) for v in last.values()) / max(len(last), 1)),
                    "host_copy_equals_device_records": ok,
                    "what": "this rank, after the timed region: the timed loop with every pair's inlier records "
-                           "also written to pinned host memory behind its batch, on a side stream"}
+                           "also copied to pinned host memory behind its batch, on a side stream"}
 
     # ceiling on this box: the same sweep with its MFMAs and LDS fragment reads
     # only (no digest, no DMA, no barrier; results are garbage and unused).  That
@@ -753,11 +772,12 @@ def main():
             # work of its own), then the same calls again with them for the kernels' durations
             reps2 = 10
             ctx.synchronize()
-            t2 = time.perf_counter()
-            for _ in range(reps2):
-                g2, i2 = matcher.match_pairs(ctx, im2, one, _synth.REF_K, **kw2)
-            ctx.synchronize()
-            wall2 = (time.perf_counter() - t2) / reps2
+            with no_gc_pause():
+                t2 = time.perf_counter()
+                for _ in range(reps2):
+                    g2, i2 = matcher.match_pairs(ctx, im2, one, _synth.REF_K, **kw2)
+                ctx.synchronize()
+                wall2 = (time.perf_counter() - t2) / reps2
             ctx.profile_select(None)
             ctx.profile_enable(True)
             ctx.profile_reset()

@@ -429,8 +429,12 @@ int sfm_gpu_match_pairs_pose(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int
  *   inlier_matches_host  optional PINNED host memory of the same shape
  *                     (hipHostMalloc / hipHostRegister; SFM_GPU_ERR_ARG otherwise):
  *                     behind the batch, on a stream of its own so that the next
- *                     batch is not held up, a kernel writes exactly the records
- *                     that exist into it; valid once the matching _end has returned.
+ *                     batch is not held up, the records travel into it; valid once
+ *                     the matching _end has returned.  Entries at and beyond a pair's
+ *                     n_inliers are unspecified (left alone, or equal to the device
+ *                     buffer's: when another batch has been begun meanwhile the whole
+ *                     record area crosses as one DMA copy beside that batch's sweep,
+ *                     otherwise a kernel writes just the records that exist).
  */
 int sfm_gpu_match_pairs_begin(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images,
                               const int32_t* pairs, int n_pairs, const sfm_gpu_match_params* params);

@@ -563,6 +563,10 @@ static int mp_enqueue(sfm_gpu_ctx* ctx, const MpPlan& pl, sfm_gpu_image* const* 
         memcpy(at, blob.data(), blob_b);
         ctx->up_used += blob_pad;
         SFM_HIP(ctx, launch_upload_block(s, djobs, at, blob_b, ctx->redo.as<int32_t>(), pl.redo_b, g));
+        if (ctx->want_up_ev) {
+            SFM_HIP(ctx, hipEventRecord(ctx->up_ev, s));
+            ctx->want_up_ev = false;
+        }
     } else {
         SFM_HIP(ctx, hipMemsetAsync(ctx->redo.p, 0, pl.redo_b * g, s));
         SFM_HIP(ctx, hipMemcpyAsync(djobs, blob.data(), blob_b, hipMemcpyHostToDevice, s));
@@ -803,6 +807,28 @@ int sfm_gpu_match_pairs_pose(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int
                             match_capacity, &po);
 }
 
+// Puts the copy of a batch's records to the host on the side stream, behind the batch (and, with
+// after_upload, behind the descriptor upload of the batch that follows it on the context's stream).
+static int mp_enqueue_record_copy(sfm_gpu_ctx* ctx, sfm_gpu_ctx::MpSlot& slot, bool after_upload)
+{
+    SFM_HIP(ctx, hipStreamWaitEvent(ctx->rec_stream, slot.ev, 0));
+    if (after_upload) {
+        // Beside the next batch's sweep: the whole record area by a plain copy (the DMA engines; the
+        // records that exist are a third of it on the bench's data), because a kernel that writes just
+        // those would take wavefront slots from the sweep for as long as the bytes take to cross the bus
+        // (measured: the sweep 35-40 us longer per batch).
+        SFM_HIP(ctx, hipStreamWaitEvent(ctx->rec_stream, ctx->up_ev, 0));
+        SFM_HIP(ctx, hipMemcpyAsync(slot.records_host, slot.records_dev,
+                                    sizeof(sfm_gpu_dmatch) * (size_t)slot.match_capacity * (size_t)slot.n_pairs,
+                                    hipMemcpyDeviceToHost, ctx->rec_stream));
+    } else {
+        SFM_HIP(ctx, launch_records_to_host(ctx->rec_stream, slot.records_dev, slot.records_host_dev,
+                                            (size_t)slot.match_capacity, slot.res.as<int32_t>(), slot.n_pairs));
+    }
+    SFM_HIP(ctx, hipEventRecord(slot.rec_ev, ctx->rec_stream));
+    return SFM_GPU_OK;
+}
+
 static int match_pairs_begin_impl(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images, int n_images, const int32_t* pairs,
                                   int n_pairs, const sfm_gpu_match_params* params, sfm_gpu_dmatch* records_dev,
                                   int match_capacity, sfm_gpu_dmatch* records_host)
@@ -842,9 +868,22 @@ static int match_pairs_begin_impl(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images
     std::vector<PairDev> pds;
     ctx->up_stage = &slot.stage;  // this slot's previous batch has been ended
     ctx->up_used = 0;
+    if (ctx->rec_deferred) {
+        if (!ctx->up_ev) SFM_HIP(ctx, hipEventCreateWithFlags(&ctx->up_ev, hipEventDisableTiming));
+        ctx->want_up_ev = true;
+    }
     rc = mp_enqueue(ctx, pl, images, pairs, 0, n_pairs, params, records_dev != nullptr, match_capacity, pds,
                     slot.res.p, records_dev, true);
     ctx->up_stage = nullptr;
+    const bool up_recorded = ctx->rec_deferred && !ctx->want_up_ev;
+    ctx->want_up_ev = false;
+    if (ctx->rec_deferred) {
+        // the batch before this one owes its records to the host: they travel while this batch's sweep runs
+        sfm_gpu_ctx::MpSlot& prev = *ctx->rec_deferred;
+        ctx->rec_deferred = nullptr;
+        const int rc2 = mp_enqueue_record_copy(ctx, prev, up_recorded);
+        if (rc2) return rc2;
+    }
     if (rc) return rc;
     SFM_HIP(ctx, hipEventRecord(slot.ev, ctx->stream));
     slot.rec_pending = false;
@@ -855,18 +894,17 @@ static int match_pairs_begin_impl(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images
     slot.params = *params;
     slot.records_dev = records_dev;
     slot.records_host_dev = host_dev;
+    slot.records_host = records_host;
     slot.match_capacity = match_capacity;
+    slot.n_pairs = n_pairs;
     if (records_host) {
-        // behind the batch, on a stream of its own: the next batch starts on the
-        // context's stream while these records travel.  The counts are read from
-        // this slot's pinned block, which nothing overwrites before _end.
-        SFM_HIP(ctx, hipStreamWaitEvent(ctx->rec_stream, slot.ev, 0));
-        SFM_HIP(ctx, launch_records_to_host(ctx->rec_stream, records_dev, host_dev, (size_t)match_capacity,
-                                            slot.res.as<int32_t>(), n_pairs));
-        SFM_HIP(ctx, hipEventRecord(slot.rec_ev, ctx->rec_stream));
+        // Behind the batch, on a stream of its own: the next batch runs on the context's stream
+        // while these records travel.  The copy is enqueued by the next _begin, or by _end if
+        // that comes first (see rec_deferred).  The counts are read from this slot's pinned
+        // block, which nothing overwrites before _end.
+        ctx->rec_deferred = &slot;
         slot.rec_pending = true;
     }
-    slot.n_pairs = n_pairs;
     ctx->mp_next ^= 1;
     ++ctx->mp_outstanding;
     return SFM_GPU_OK;
@@ -910,6 +948,11 @@ int sfm_gpu_match_pairs_end(sfm_gpu_ctx* ctx, int32_t* n_good, int32_t* n_inlier
     sfm_gpu_ctx::MpSlot& slot = ctx->mp_slot[ctx->mp_outstanding == 2 ? ctx->mp_next : ctx->mp_next ^ 1];
     if (capacity < slot.n_pairs)
         return ctx->fail(SFM_GPU_ERR_CAPACITY, "the oldest batch has %d pairs, room for %d", slot.n_pairs, capacity);
+    if (ctx->rec_deferred == &slot) {
+        ctx->rec_deferred = nullptr;
+        const int rc0 = mp_enqueue_record_copy(ctx, slot, false);
+        if (rc0) return rc0;
+    }
     SFM_HIP(ctx, hipEventSynchronize(slot.ev));
     if (slot.rec_pending) SFM_HIP(ctx, hipEventSynchronize(slot.rec_ev));
     bool again = false;

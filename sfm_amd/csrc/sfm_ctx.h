@@ -188,6 +188,7 @@ struct sfm_gpu_ctx {
         sfm_gpu_match_params params;
         sfm_gpu_dmatch* records_dev = nullptr;
         sfm_gpu_dmatch* records_host_dev = nullptr;
+        sfm_gpu_dmatch* records_host = nullptr;  // the same buffer by the caller's address
         int match_capacity = 0;
         // sfm_gpu_match_pairs' own groups: device addresses of the group's pairs, and
         // the group's inlier records when the caller wants them on the host
@@ -201,6 +202,13 @@ struct sfm_gpu_ctx {
     // side stream on which a batch's inlier records travel to the host while the
     // next batch already runs on `stream` (created on first use)
     hipStream_t rec_stream = nullptr;
+    // The copy of a batch's records is put on rec_stream when the NEXT batch begins, gated on
+    // up_ev (recorded behind that batch's descriptor upload), or by _end if no batch followed:
+    // the upload reads pinned host memory, and a read request issued while the records are
+    // being written to the host queues behind all of those writes.
+    MpSlot* rec_deferred = nullptr;
+    hipEvent_t up_ev = nullptr;
+    bool want_up_ev = false;
     // recorded behind the sweep and the neighbour extraction of every pair batch
     // once another context has asked to wait for it (sfm_gpu_stream_wait_front)
     hipEvent_t front_ev = nullptr;

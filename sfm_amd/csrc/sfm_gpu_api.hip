@@ -322,6 +322,7 @@ void sfm_gpu_destroy(sfm_gpu_ctx* c)
         slot.rec.release();
     }
     if (c->front_ev) (void)hipEventDestroy(c->front_ev);
+    if (c->up_ev) (void)hipEventDestroy(c->up_ev);
     for (auto& u : c->up_ring) {
         if (u.ev) (void)hipEventDestroy(u.ev);
         u.buf.release();

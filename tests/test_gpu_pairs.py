@@ -532,7 +532,10 @@ def test_begin_end_leaves_each_pairs_select_matches_on_device_and_host(gpu_ctx, 
             for p in range(len(g)):
                 assert h[p, :i[p]].tobytes() == sel[p].tobytes()
                 assert d[p, :i[p]].tobytes() == sel[p].tobytes()
-                assert (host[name][p, i[p]:] == -9).all()        # nothing beyond the records travels
+                # beyond a pair's records the host buffer is unspecified: untouched, or the bytes of the
+                # device buffer (the batch's whole record area may travel as one copy)
+                rest = host[name][p, i[p]:]
+                assert ((rest == -9) | (rest == -7)).all()
             host[name].fill_(-9)
             dev[name].fill_(-7)
         torch.cuda.synchronize()
