@@ -209,6 +209,10 @@ def main():
                     help="HIP priority of the stream the matching runs on (-1: above the conversion's side stream)")
     ap.add_argument("--no-overlap-probe", action="store_true",
                     help="skip the two-stream reference measurement after the timed region")
+    ap.add_argument("--no-records-to-host", action="store_true",
+                    help="skip the block that repeats the loop with the records also copied to the host (a kernel "
+                         "trace of the run then holds the timed loop's launches only: under the profiler that copy is "
+                         "a shader kernel beside the sweep)")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="contexts / HIP streams that consecutive steps alternate over (1: one stream, "
                          "kernels never overlap and their durations are their own)")
@@ -561,7 +565,7 @@ def main():
     # host that consumes selectMatches on the CPU, as the reference's later stages
     # do, would see.
     to_host = None
-    if args.records and args.streams == 1:
+    if args.records and args.streams == 1 and not args.no_records_to_host:
         stage[0] = "records to host"
         run_steps(4, to_host=True)
         torch.cuda.synchronize()

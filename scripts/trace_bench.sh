@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/trace_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench --output-format csv -- python3 $REPO/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-microkernel --no-overlap-probe --no-configs2 --no-allpairs "$@" > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench --output-format csv -- python3 $REPO/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-microkernel --no-overlap-probe --no-records-to-host --no-configs2 --no-allpairs "$@" > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 f=$(find "$OUT/trace" -name '*kernel_stats.csv' | head -1)
 cp "$f" "$OUT/kernel_stats.csv"
 python3 - "$OUT/kernel_stats.csv" <<'PY'
