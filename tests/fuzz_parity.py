@@ -230,14 +230,34 @@ def trial_pairs(ctx, rng, idx, stats):
         ng, ni, sel = matcher.match_pairs(ctx, imgs, pairs, K, want_matches=True, **kw)
         if rng.integers(0, 2):
             # the same batch through the enqueue / collect entry points, twice in flight
-            b = matcher.PairBatch(ctx, imgs, pairs, K, **kw)
-            b.begin()
-            b.begin()
-            for _ in range(2):
-                g2, i2 = b.end()
+            # (half of the time with each pair's records left on the device and copied to pinned host memory)
+            rec = bool(rng.integers(0, 2))
+            cap = max(sizes)
+            if rec:
+                import torch
+                from sfm_amd import _lib
+                dev = [torch.full((len(pairs), cap, 4), -7, dtype=torch.int32, device="cuda") for _ in range(2)]
+                host = [torch.full((len(pairs), cap, 4), -9, dtype=torch.int32).pin_memory() for _ in range(2)]
+                torch.cuda.synchronize()
+                bs = [matcher.PairBatch(ctx, imgs, pairs, K, records_dev=d.data_ptr(), match_capacity=cap,
+                                        records_host=h.data_ptr(), **kw) for d, h in zip(dev, host)]
+            else:
+                bs = [matcher.PairBatch(ctx, imgs, pairs, K, **kw)] * 2
+            bs[0].begin()
+            bs[1].begin()
+            for t in range(2):
+                g2, i2 = bs[t].end()
                 if not ((g2 == ng).all() and (i2 == ni).all()):
                     print("MISMATCH pairs #%d: begin/end counts differ from the blocking call" % idx, flush=True)
                     return 1
+                if rec:
+                    ctx.synchronize()
+                    h = host[t].numpy().view(_lib.DMATCH_DTYPE).reshape(len(pairs), cap)
+                    d = dev[t].cpu().numpy().view(_lib.DMATCH_DTYPE).reshape(len(pairs), cap)
+                    for p in range(len(pairs)):
+                        if not (h[p, :ni[p]].tobytes() == sel[p].tobytes() and d[p, :ni[p]].tobytes() == sel[p].tobytes()):
+                            print("MISMATCH pairs #%d: begin/end records differ from the blocking call's" % idx, flush=True)
+                            return 1
     finally:
         for im in imgs:
             im.close()
@@ -349,6 +369,8 @@ def run(seconds, seed, only="", ctx=None, quiet=False, score_prune=None):
     rng = np.random.default_rng(seed)
     own = ctx is None
     if own:
+        import torch
+        torch.cuda.init()   # before the first context (the pipeline trials keep record buffers in torch tensors)
         ctx = matcher.Context(0)
     if score_prune is not None:
         ctx.check(ctx._L.sfm_gpu_debug_set_score_prune(ctx.handle, int(score_prune)))
