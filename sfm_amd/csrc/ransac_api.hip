@@ -869,7 +869,8 @@ static int match_pairs_begin_impl(sfm_gpu_ctx* ctx, sfm_gpu_image* const* images
     ctx->up_stage = &slot.stage;  // this slot's previous batch has been ended
     ctx->up_used = 0;
     if (ctx->rec_deferred) {
-        if (!ctx->up_ev) SFM_HIP(ctx, hipEventCreateWithFlags(&ctx->up_ev, hipEventDisableTiming));
+        if (!ctx->up_ev)
+            SFM_HIP(ctx, hipEventCreateWithFlags(&ctx->up_ev, hipEventDisableTiming | hipEventDisableSystemFence));
         ctx->want_up_ev = true;
     }
     rc = mp_enqueue(ctx, pl, images, pairs, 0, n_pairs, params, records_dev != nullptr, match_capacity, pds,
@@ -935,7 +936,10 @@ int sfm_gpu_stream_wait_front(sfm_gpu_ctx* waiter, sfm_gpu_ctx* source)
     if (waiter->device != source->device)
         return waiter->fail(SFM_GPU_ERR_ARG, "the two contexts are on different devices");
     SFM_HIP(waiter, hipSetDevice(source->device));
-    if (!source->front_ev) SFM_HIP(waiter, hipEventCreateWithFlags(&source->front_ev, hipEventDisableTiming));
+    // (orders work of one device only: no system-scope release, whose write-back and invalidation
+    // would be paid by the kernels behind the record)
+    if (!source->front_ev)
+        SFM_HIP(waiter, hipEventCreateWithFlags(&source->front_ev, hipEventDisableTiming | hipEventDisableSystemFence));
     if (source->front_recorded) SFM_HIP(waiter, hipStreamWaitEvent(waiter->stream, source->front_ev, 0));
     return SFM_GPU_OK;
 }
